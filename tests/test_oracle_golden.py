@@ -1,0 +1,108 @@
+"""CPU: the oracle (oracle/pcb_oracle.c) against the reference's own outputs (tests/golden)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.helpers import load_golden, knn_tie_tolerant_mismatch
+
+CASES = ["ops_grid", "ops_cont", "ops_dup", "ops_tiny"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fps_bit_identical(name):
+    g = load_golden(name)
+    S = g["fps_idx"].shape[1]
+    got = orc.farthest_point_sample(g["xyz"], S, g["fps_start"])
+    assert np.array_equal(got, g["fps_idx"])
+    assert np.array_equal(orc.index_points(g["xyz"], got), g["new_xyz"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_ball_query_bit_identical(name):
+    g = load_golden(name)
+    for t in (0, 1):
+        got = orc.query_ball_point(float(g[f"ball{t}_r"]), int(g[f"ball{t}_ns"]), g["xyz"], g["new_xyz"])
+        assert np.array_equal(got, g[f"ball{t}_idx"]), f"ball{t}"
+
+
+def test_ball_query_no_point_in_radius_yields_N():
+    g = load_golden("ops_misc")
+    got = orc.query_ball_point(0.3, 8, g["empty_xyz"], g["empty_new_xyz"])
+    assert np.array_equal(got, g["empty_idx"])
+    assert (got == g["empty_xyz"].shape[1]).all()
+
+
+def test_square_distance_bitwise():
+    g = load_golden("ops_misc")
+    got = orc.square_distance(g["sd_src"], g["sd_dst"])
+    assert np.array_equal(got.view(np.int32), g["sd_out"].view(np.int32))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_three_nn(name):
+    g = load_golden(name)
+    for k in (3, 4):
+        d, i = orc.three_nn(g["xyz"], g["new_xyz"], k)
+        assert np.array_equal(d.view(np.int32), g["nn_d"][:, :, :k].view(np.int32))  # distances bit-exact
+        if name == "ops_dup":
+            # duplicated points: equal distances, order among them is the sort's choice
+            sd = orc.square_distance(g["xyz"], g["new_xyz"])
+            bad = knn_tie_tolerant_mismatch(i, g["nn_idx"][:, :, :k], lambda b, n, js: sd[b, n, js])
+            assert bad == 0
+        else:
+            assert np.array_equal(i, g["nn_idx"][:, :, :k])
+
+
+def test_three_nn_tie_order_is_stable_like_reference():
+    g = load_golden("ops_dup")
+    _, i = orc.three_nn(g["xyz"], g["new_xyz"], 4)
+    assert np.array_equal(i, g["nn_idx"])  # reference CPU sort is stable: lowest index first
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_knn_xyz(name):
+    g = load_golden(name)
+    k = int(g["knn_k"])
+    idx, d = orc.knn(g["xyz"], k, return_dist=True)
+    ref = g["knn_idx"]
+    x = g["xyz"]
+
+    def dist_of(b, i, js):
+        return orc.square_distance(x[b:b + 1, i:i + 1], x[b:b + 1, js])[0, 0]
+
+    assert knn_tie_tolerant_mismatch(idx, ref, dist_of, atol=1e-6) == 0
+    if name in ("ops_grid", "ops_cont"):
+        assert (idx != ref).mean() < 2e-3
+
+
+def test_knn_feature_space_d64():
+    g = load_golden("ops_misc")
+    x = np.ascontiguousarray(g["knn64_x"].transpose(0, 2, 1))
+    idx, d = orc.knn(x, 20, return_dist=True)
+    ref = g["knn64_idx"]
+    x64 = x.astype(np.float64)
+
+    def dist_of(b, i, js):
+        return ((x64[b, js] - x64[b, i]) ** 2).sum(-1)
+
+    # the reference's blocked sgemm rounds differently at D = 64: allow swaps of near-equal distances
+    assert knn_tie_tolerant_mismatch(idx, ref, dist_of, rtol=1e-5, atol=1e-4) == 0
+    assert (idx != ref).mean() < 1e-3
+
+
+def test_edge_features():
+    g = load_golden("ops_misc")
+    x = np.ascontiguousarray(g["graph_x"].transpose(0, 2, 1))
+    got = orc.edge_features(x, g["graph_idx"])
+    assert np.array_equal(got, g["graph_out"])
+
+
+@pytest.mark.parametrize("k", [3, 4])
+def test_interpolate(k):
+    g = load_golden("ops_misc")
+    d, i = orc.three_nn(g["interp_xyz1"], g["interp_xyz2"], k)
+    assert np.array_equal(i, g[f"interp{k}_idx"])
+    assert np.array_equal(d, g[f"interp{k}_d"])
+    out, w = orc.three_interpolate(g["interp_p2"], d, i, return_weight=True)
+    np.testing.assert_allclose(w, g[f"interp{k}_w"], rtol=2e-7, atol=0)
+    np.testing.assert_allclose(out, g[f"interp{k}_out"], rtol=1e-6, atol=1e-6)
