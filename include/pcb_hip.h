@@ -1,0 +1,169 @@
+/*
+ * pcb_hip.h -- C ABI of libpcb_hip.so, the MI355X (gfx950) implementation of the
+ * PointNet++ set-abstraction / feature-propagation operators and the DGCNN kNN / EdgeConv
+ * operator of UT-Team-Chun/Pointcloud-bridge.
+ *
+ * The reference has no FFI for this path: the operators are ATen compositions inside two Python
+ * files.  Each entry point below replaces one of those compositions and names it
+ * (paths relative to the reference's Highway_bridge/ directory).  INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; outputs are pre-allocated; the
+ *     library allocates nothing and keeps no state (re-entrant per stream)
+ *   - tensors are dense row-major with the shapes written next to each argument
+ *   - indices are int64 at the boundary, as in the reference (torch.long)
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work
+ *   - return value: PCB_OK (0) or a negative pcb_status; no exceptions cross the boundary
+ */
+#ifndef PCB_HIP_H
+#define PCB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pcb_status {
+    PCB_OK = 0,
+    PCB_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, k or nsample out of range */
+    PCB_ERR_UNSUPPORTED = -2, /* size outside what the kernels are built for (see each call) */
+    PCB_ERR_LAUNCH = -3       /* hipGetLastError() reported a failure after the launch */
+} pcb_status;
+
+/* Library/ABI version (major*100 + minor). */
+int pcb_version(void);
+
+/* Text for a pcb_status value (static storage). */
+const char *pcb_status_string(int status);
+
+/*
+ * Pairwise squared distances, materialised.  Replaces square_distance,
+ * models/pointnet2_utils.py:7-14, for callers that want the matrix itself (none of the operators
+ * below do).  src [B,N,3], dst [B,M,3] -> out [B,N,M] fp32, d = ((-2*dot) + |s|^2) + |t|^2.
+ */
+int pcb_square_distance(const float *src, const float *dst, int B, int N, int M, float *out,
+                        void *stream);
+
+/*
+ * Farthest point sampling.  Replaces farthest_point_sample, models/pointnet2_utils.py:63-80.
+ *   xyz       [B,N,3] fp32
+ *   start_idx [B] int64   first sample per scene: the value the reference draws with
+ *                         torch.randint on the CPU generator (:69); the caller draws it
+ *   out_idx   [B,S] int64
+ * Distances are ((dx*dx + dy*dy) + dz*dz) in fp32, the running minimum is updated on strict
+ * "<", the next sample is the FIRST index of the maximum -- bit-identical to the reference.
+ * Supported: 1 <= N <= 40960 (one workgroup per scene; N <= 16384 keeps the cloud in registers).
+ */
+int pcb_fps(const float *xyz, int B, int N, int S, const int64_t *start_idx, int64_t *out_idx,
+            void *stream);
+
+/*
+ * Ball query.  Replaces query_ball_point, models/pointnet2_utils.py:97-112 (and the
+ * square_distance call inside it, :7-14, which is never materialised here).
+ *   xyz [B,N,3], new_xyz [B,S,3] fp32;  r2 = (float)(radius*radius);  out_idx [B,S,nsample] int64
+ * For each centroid: the first `nsample` indices i (ascending) with d(i) <= r2, where
+ * d = ((-2*dot) + |c|^2) + |p|^2, dot = fma(cz,pz, fma(cy,py, cx*px)); missing slots repeat the
+ * first hit; a centroid with no hit gets N in every slot (as the reference leaves it).
+ * Requires 1 <= nsample <= N.
+ */
+int pcb_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float r2,
+                   int nsample, int64_t *out_idx, void *stream);
+
+/*
+ * Two radii in one pass over the cloud (MultiScaleSetAbstraction.forward runs query_ball_point
+ * once per radius on the same centroids, models/pointnet2_utils.py:340-341).  Same results as two
+ * pcb_ball_query calls.
+ */
+int pcb_ball_query2(const float *xyz, const float *new_xyz, int B, int N, int S,
+                    float r2_a, int nsample_a, int64_t *out_idx_a,
+                    float r2_b, int nsample_b, int64_t *out_idx_b, void *stream);
+
+/*
+ * Row gather with index clamp.  Replaces index_points, models/pointnet2_utils.py:17-39.
+ *   points [B,N,C] fp32, idx [B,M] int64 (clamped to [0,N-1] as :34-36), out [B,M,C]
+ */
+int pcb_gather_rows(const float *points, const int64_t *idx, int B, int N, int C, int M,
+                    float *out, void *stream);
+
+/*
+ * Backward of pcb_gather_rows: grad_points[b, clamp(idx[b,m]), :] += grad_out[b,m,:].
+ * grad_points [B,N,C] must be zero-filled (or hold the value to accumulate onto) by the caller.
+ */
+int pcb_gather_rows_bwd(const float *grad_out, const int64_t *idx, int B, int N, int C, int M,
+                        float *grad_points, void *stream);
+
+/*
+ * Grouping of sample_and_group / MultiScaleSetAbstraction, models/pointnet2_utils.py:51-58 and
+ * :342-349: out[b,s,j,:] = cat(xyz[b,idx[b,s,j]] - new_xyz[b,s], feat[b,idx[b,s,j]]).
+ *   xyz [B,N,3], new_xyz [B,S,3], feat [B,N,C] or NULL (C = 0), idx [B,S,ns] int64 (clamped),
+ *   out [B,S,ns,3+C] fp32
+ */
+int pcb_group_points(const float *xyz, const float *new_xyz, const float *feat, const int64_t *idx,
+                     int B, int N, int S, int ns, int C, float *out, void *stream);
+
+/*
+ * Backward of pcb_group_points w.r.t. feat: grad_feat[b,idx,c] += grad_out[b,s,j,3+c].
+ * grad_feat [B,N,C] zero-filled by the caller.  (xyz carries no gradient: it is input data.)
+ */
+int pcb_group_points_bwd(const float *grad_out, const int64_t *idx, int B, int N, int S, int ns,
+                         int C, float *grad_feat, void *stream);
+
+/*
+ * k nearest centroids for interpolation.  Replaces square_distance + full sort + [:k] in
+ * FeaturePropagation.forward (k = 3, models/pointnet2_utils.py:185-188) and
+ * EnhancedFeaturePropagation.forward (k = 4, :253-256).
+ *   xyz1 [B,N,3] queries, xyz2 [B,S,3] candidates, out_d2 [B,N,k] fp32, out_idx [B,N,k] int64
+ * Ascending distance; equal distances keep ascending index order (the reference's CPU sort is
+ * stable).  Distances are the unclamped expansion-formula values (may be slightly negative).
+ * Requires 1 <= k <= 4 and S >= k.
+ */
+int pcb_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int k, float *out_d2,
+                 int64_t *out_idx, void *stream);
+
+/*
+ * Inverse-distance interpolation, models/pointnet2_utils.py:191-196 / :259-267:
+ *   w = 1/(d2 + 1e-8); w /= sum_k w; out[b,n,:] = sum_k w_k * feat[b,idx[b,n,k],:]
+ *   feat [B,S,C], d2/idx [B,N,k], out [B,N,C], out_w [B,N,k] (optional, NULL to skip)
+ */
+int pcb_interpolate(const float *feat, const float *d2, const int64_t *idx, int B, int N, int S,
+                    int C, int k, float *out, float *out_w, void *stream);
+
+/*
+ * Backward of pcb_interpolate w.r.t. feat: grad_feat[b,idx[b,n,q],:] += w[b,n,q]*grad_out[b,n,:].
+ * grad_feat [B,S,C] zero-filled by the caller.
+ */
+int pcb_interpolate_bwd(const float *grad_out, const float *w, const int64_t *idx, int B, int N,
+                        int S, int C, int k, float *grad_feat, void *stream);
+
+/*
+ * kNN graph.  Replaces DGCNN.knn, models/DGCNN.py:49-70 (the [B,N,N] matrix is never stored).
+ *   x [B,N,D] fp32 (the reference transposes its [B,D,N] input to this layout first, :60)
+ *   out_idx [B,N,k] int64, nearest first (slot 0 is the point itself on duplicate-free data)
+ * pd(i,j) = (|xi|^2 + (-2*<xi,xj>)) + |xj|^2 with <,> an fma chain in channel order and |x|^2 a
+ * left-to-right sum of squares; the k smallest pd, ties by lower index.
+ * Requires 1 <= k <= 32, k <= N, 1 <= D <= 128.
+ */
+int pcb_knn(const float *x, int B, int N, int D, int k, int64_t *out_idx, void *stream);
+
+/*
+ * EdgeConv edge features.  Replaces the gather/repeat/cat of DGCNN.get_graph_feature,
+ * models/DGCNN.py:90-107: out[b,n,j,:] = cat(x[b,idx[b,n,j]] - x[b,n], x[b,n]).
+ *   x [B,N,D], idx [B,N,k] int64, out [B,N,k,2D]   (channels-last; the reference's [B,2D,N,k]
+ *   is out.permute(0,3,1,2))
+ */
+int pcb_edge_features(const float *x, const int64_t *idx, int B, int N, int D, int k, float *out,
+                      void *stream);
+
+/*
+ * Backward of pcb_edge_features: grad_x[b,idx,c] += g[b,n,j,c];
+ * grad_x[b,n,c] += sum_j (g[b,n,j,D+c] - g[b,n,j,c]).  grad_x [B,N,D] zero-filled by the caller.
+ */
+int pcb_edge_features_bwd(const float *grad_out, const int64_t *idx, int B, int N, int D, int k,
+                          float *grad_x, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCB_HIP_H */

@@ -1,0 +1,60 @@
+"""ctypes binding of libpcb_hip.so (C ABI: include/pcb_hip.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcb_hip.so")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes, exactly the declarations of include/pcb_hip.h
+SIGNATURES = {
+    "pcb_version": [],
+    "pcb_status_string": [_i],
+    "pcb_square_distance": [_p, _p, _i, _i, _i, _p, _p],
+    "pcb_fps": [_p, _i, _i, _i, _p, _p, _p],
+    "pcb_ball_query": [_p, _p, _i, _i, _i, _f, _i, _p, _p],
+    "pcb_ball_query2": [_p, _p, _i, _i, _i, _f, _i, _p, _f, _i, _p, _p],
+    "pcb_gather_rows": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "pcb_gather_rows_bwd": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "pcb_group_points": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_group_points_bwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_three_nn": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_interpolate": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_interpolate_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_knn": [_p, _i, _i, _i, _i, _p, _p],
+    "pcb_edge_features": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "pcb_edge_features_bwd": [_p, _p, _i, _i, _i, _i, _p, _p],
+}
+
+_lib = None
+
+
+class PcbError(RuntimeError):
+    """A libpcb_hip.so entry point returned a negative pcb_status."""
+
+
+def load():
+    """Load libpcb_hip.so; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP kernels are not built. "
+                "Run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
+                "This package has no CPU or eager fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the build lacks a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == "pcb_status_string" else ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pcb_status_string(status).decode()
+        raise PcbError(f"{what}: {msg} (status {status})")

@@ -1,0 +1,88 @@
+"""Drop-in for Highway_bridge/models/DGCNN.py of UT-Team-Chun/Pointcloud-bridge.
+
+Same class name, constructor, methods (knn, get_graph_feature, forward), tensor layouts and
+state_dict keys (including the doubled BatchNorm entries bn1.* / conv1.1.* that come from the
+reference reusing self.bnX inside self.convX, DGCNN.py:12-33).  The dynamic graph (kNN in feature
+space, rebuilt before every EdgeConv block) and the edge-feature gather run as gfx950 kernels
+(..ops -> libpcb_hip.so); the [B,N,N] distance matrix of the reference never exists.
+
+Activations are channels-last ([rows, C]) internally; the EdgeConv 1x1 convolutions are row GEMMs
+over the parameters of the stock nn.Conv2d / nn.BatchNorm2d sub-modules.  GPU only.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .pointnet2_utils import _bn_rows, _conv_rows
+
+
+class DGCNN(nn.Module):
+    def __init__(self, num_classes=5, k=20):
+        super().__init__()
+        self.k = k
+        self.bn1 = nn.BatchNorm2d(64)
+        self.bn2 = nn.BatchNorm2d(64)
+        self.bn3 = nn.BatchNorm2d(64)
+        self.bn4 = nn.BatchNorm2d(128)
+        self.bn5 = nn.BatchNorm1d(1024)
+
+        def edge_block(cin, cout, bn):
+            return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False), bn,
+                                 nn.LeakyReLU(negative_slope=0.2))
+
+        self.conv1 = edge_block(6, 64, self.bn1)
+        self.conv2 = edge_block(64 * 2, 64, self.bn2)
+        self.conv3 = edge_block(64 * 2, 64, self.bn3)
+        self.conv4 = edge_block(64 * 2, 128, self.bn4)
+        self.conv5 = nn.Sequential(nn.Conv1d(320, 1024, kernel_size=1, bias=False), self.bn5,
+                                   nn.LeakyReLU(negative_slope=0.2))
+        self.local_bn = nn.BatchNorm1d(320)
+        self.point_conv = nn.Sequential(
+            nn.Conv1d(1344, 512, 1), nn.BatchNorm1d(512), nn.LeakyReLU(negative_slope=0.2),
+            nn.Conv1d(512, 256, 1), nn.BatchNorm1d(256), nn.LeakyReLU(negative_slope=0.2),
+            nn.Conv1d(256, num_classes, 1))
+
+    # -- reference API ------------------------------------------------------------------------
+    def knn(self, x, k):
+        """x [B,D,N] -> idx [B,N,k] int64, nearest first (reference DGCNN.py:49-70)."""
+        return ops.knn(x.transpose(2, 1).contiguous(), k)
+
+    def get_graph_feature(self, x, k=20, idx=None):
+        """x [B,D,N] -> cat(x_j - x_i, x_i) as [B,2D,N,k] (reference DGCNN.py:72-109)."""
+        xt = x.transpose(2, 1).contiguous()
+        if idx is None:
+            idx = ops.knn(xt, k)
+        return ops.edge_features(xt, idx).permute(0, 3, 1, 2)
+
+    # -- forward ------------------------------------------------------------------------------
+    @staticmethod
+    def _lrelu(x):
+        return F.leaky_relu(x, negative_slope=0.2)
+
+    def _edge_conv(self, block, x, k):
+        """x [B,N,D] channels-last -> [B,N,Cout]: kNN graph, edge features, conv+BN+LeakyReLU, max."""
+        B, N, D = x.shape
+        idx = ops.knn(x, k)
+        e = ops.edge_features(x, idx).view(B * N * k, 2 * D)
+        y = self._lrelu(_bn_rows(block[1], _conv_rows(block[0], e)))
+        return y.view(B, N, k, -1).max(dim=2)[0]
+
+    def forward(self, xyz, features=None):
+        """xyz [B,N,3], features [B,N,C] (ignored, as in the reference :123-128) -> logits [B,N,classes]."""
+        B, N, _ = xyz.shape
+        x0 = xyz[:, :, :3].contiguous()
+        k = min(self.k, N - 1)  # reference :131
+        x1 = self._edge_conv(self.conv1, x0, k)
+        x2 = self._edge_conv(self.conv2, x1, k)
+        x3 = self._edge_conv(self.conv3, x2, k)
+        x4 = self._edge_conv(self.conv4, x3, k)
+        local = torch.cat((x1, x2, x3, x4), dim=2).view(B * N, 320)
+        local_norm = self._lrelu(_bn_rows(self.local_bn, local))
+        g = self._lrelu(_bn_rows(self.conv5[1], _conv_rows(self.conv5[0], local)))
+        g = g.view(B, N, 1024).max(dim=1, keepdim=True)[0]  # adaptive_max_pool1d(x, 1), :160
+        pf = torch.cat([local_norm.view(B, N, 320), g.expand(-1, N, -1)], dim=2).view(B * N, 1344)
+        pc = self.point_conv
+        pf = self._lrelu(_bn_rows(pc[1], _conv_rows(pc[0], pf)))
+        pf = self._lrelu(_bn_rows(pc[4], _conv_rows(pc[3], pf)))
+        return _conv_rows(pc[6], pf).view(B, N, -1)

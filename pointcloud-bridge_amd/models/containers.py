@@ -1,0 +1,113 @@
+"""Segmentation networks assembled from the drop-in operators.
+
+The reference's container files (Highway_bridge/models/model.py, models/pointnet2.py) only wire
+SetAbstraction / FeaturePropagation modules together and work unchanged on top of
+`pointnet2_utils`.  They do not travel to the GPU box, so the benchmark, smoke test and parity
+tests use these equivalents; attribute names (sa1..3, fp3..1, conv1, bn1, drop1, conv2, fusion,
+final_fusion) and therefore state_dict keys match the reference classes named in each docstring.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .pointnet2_utils import (EnhancedFeaturePropagation, FeaturePropagation, MultiScaleSetAbstraction,
+                              SetAbstraction)
+
+# (npoint, radius, nsample, in_channel, mlp) -- models/model.py:17-19 == models/pointnet2.py:20-22
+_SSG_ENCODER = [
+    (1024, 0.1, 32, 6, [64, 64, 128]),
+    (256, 0.2, 32, 131, [128, 128, 256]),
+    (64, 0.4, 32, 259, [256, 256, 512]),
+]
+# (npoint, radii, nsamples, in_channel, mlp) -- models/model.py:73-76
+_MSG_ENCODER = [
+    (1024, [0.1, 0.2], [16, 32], 6, [64, 64, 128]),
+    (512, [0.2, 0.4], [16, 32], 259, [128, 128, 256]),
+    (128, [0.4, 0.8], [16, 32], 515, [256, 256, 512]),
+]
+
+
+class PointNet2(nn.Module):
+    """PointNet++ SSG segmentation net.
+
+    rgb_skip=False: `PointNet2` of models/model.py:12-56 (fp1 sees only the propagated features).
+    rgb_skip=True:  `PointNet2` of models/pointnet2.py:10-61 (fp1 also sees the raw colours, 131 ch).
+    forward(xyz [B,N,3], points [B,N,3]) -> logits [B,num_classes,N].
+    """
+
+    def __init__(self, num_classes=8, rgb_skip=False, encoder=None):
+        super().__init__()
+        self.rgb_skip = rgb_skip
+        enc = encoder or _SSG_ENCODER
+        self.sa1 = SetAbstraction(*enc[0])
+        self.sa2 = SetAbstraction(*enc[1])
+        self.sa3 = SetAbstraction(*enc[2])
+        self.fp3 = FeaturePropagation(768, [256, 256])
+        self.fp2 = FeaturePropagation(384, [256, 128])
+        self.fp1 = FeaturePropagation(128 + (3 if rgb_skip else 0), [128, 128, 128])
+        self.conv1 = nn.Conv1d(128, 128, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.drop1 = nn.Dropout(0.5)
+        self.conv2 = nn.Conv1d(128, num_classes, 1)
+
+    def forward(self, xyz, points):
+        points = points.transpose(1, 2)
+        l1_xyz, l1 = self.sa1(xyz, points)
+        l2_xyz, l2 = self.sa2(l1_xyz, l1)
+        l3_xyz, l3 = self.sa3(l2_xyz, l2)
+        l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
+        l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
+        l0 = self.fp1(xyz, l1_xyz, points if self.rgb_skip else None, l1)
+        feat = self.drop1(F.relu(self.bn1(self.conv1(l0))))
+        return self.conv2(feat)
+
+
+class MultiScaleFeatureFusion(nn.Module):
+    """models/model.py:149-167: resample every decoder level to N points, 1x1 conv each, concatenate."""
+
+    def __init__(self, in_channels_list, out_channels):
+        super().__init__()
+        self.convs = nn.ModuleList(
+            nn.Sequential(nn.Conv1d(c, out_channels, 1), nn.BatchNorm1d(out_channels), nn.ReLU())
+            for c in in_channels_list)
+
+    def forward(self, features_list):
+        n = features_list[2].shape[2]
+        return torch.cat([conv(F.interpolate(f, size=n)) for f, conv in zip(features_list, self.convs)], dim=1)
+
+
+class PointNet2MSG(nn.Module):
+    """PointNet++ MSG segmentation net = the SA/FP trunk of `EnhancedPointNet2` (BridgeSeg),
+    models/model.py:58-147: MSG encoder (:73-76), EnhancedFeaturePropagation decoder (:84-86),
+    MultiScaleFeatureFusion (:88-91) and the final_fusion head (:93-99).
+
+    The bridge-specific encoders in front of the trunk (BridgeStructureEncoding,
+    ColorFeatureExtraction, CompositeFeatureFusion, GeometricFeatureExtraction --
+    models/attention_modules.py) are outside this path; the colours
+    enter sa1 directly, which keeps its reference width of 6 channels.
+    forward(xyz [B,N,3], features [B,N,3]) -> logits [B,num_classes,N].
+    """
+
+    def __init__(self, num_classes=5, encoder=None):
+        super().__init__()
+        enc = encoder or _MSG_ENCODER
+        self.sa1 = MultiScaleSetAbstraction(*enc[0])
+        self.sa2 = MultiScaleSetAbstraction(*enc[1])
+        self.sa3 = MultiScaleSetAbstraction(*enc[2])
+        self.fp3 = EnhancedFeaturePropagation(1536, [1024, 256])
+        self.fp2 = EnhancedFeaturePropagation(512, [256, 256])
+        self.fp1 = EnhancedFeaturePropagation(256 + 3, [256, 128])
+        self.fusion = MultiScaleFeatureFusion([256, 256, 128], 128)
+        self.final_fusion = nn.Sequential(
+            nn.Conv1d(384, 128, 1), nn.BatchNorm1d(128), nn.ReLU(), nn.Dropout(0.5),
+            nn.Conv1d(128, num_classes, 1))
+
+    def forward(self, xyz, features):
+        feats = features.transpose(1, 2)
+        l1_xyz, l1 = self.sa1(xyz, feats)
+        l2_xyz, l2 = self.sa2(l1_xyz, l1)
+        l3_xyz, l3 = self.sa3(l2_xyz, l2)
+        l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
+        l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
+        l0 = self.fp1(xyz, l1_xyz, feats, l1)
+        return self.final_fusion(self.fusion([l2, l1, l0]))

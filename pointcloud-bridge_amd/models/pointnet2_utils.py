@@ -1,0 +1,250 @@
+"""Drop-in for Highway_bridge/models/pointnet2_utils.py of UT-Team-Chun/Pointcloud-bridge.
+
+Same public names, argument order, tensor layouts, int64 index dtype and state_dict keys as the
+reference module, so `from models.pointnet2_utils import SetAbstraction, FeaturePropagation,
+MultiScaleSetAbstraction, EnhancedFeaturePropagation` keeps working in the reference's containers
+(models/model.py:10, models/pointnet2.py:8).  The neighbourhood operators run as hand-written
+gfx950 kernels (..ops -> libpcb_hip.so); nothing of size [B,S,N] / [B,N,S] is materialised.
+
+Inside a module the activations are kept channels-last ([rows, C]); the 1x1 convolutions of the
+reference are evaluated as row GEMMs with the weights of the very same nn.Conv*/nn.BatchNorm*
+sub-modules (mlp_convs.*, mlp_bns.*, conv_blocks.*, bn_blocks.*, attention.*, boundary_aware.*).
+Tensors returned to the caller have the reference's shapes ([B,C,S] / [B,C,N]); they are
+transposed views of channels-last storage.
+
+GPU only: CPU tensors raise (there is no fallback path).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+# ---------------------------------------------------------------------------------------------
+# free functions (reference: pointnet2_utils.py:7-112)
+# ---------------------------------------------------------------------------------------------
+def square_distance(src, dst):
+    """[B,N,3] x [B,M,3] -> [B,N,M] squared distances (reference :7-14), materialised."""
+    return ops.square_distance(src, dst)
+
+
+def index_points(points, idx):
+    """points [B,N,C], idx [B,S] or [B,S,ns] (clamped to [0,N-1]) -> [B,S,(ns,)C] (reference :17-39)."""
+    return ops.gather_rows(points, idx)
+
+
+def farthest_point_sample(xyz, npoint):
+    """xyz [B,N,3] -> [B,npoint] int64 (reference :63-80).
+
+    Consumes exactly one torch.randint(0, N, (B,)) from the CPU default generator, like the
+    reference (:69), so seeded runs sample the same start points."""
+    B, N, _ = xyz.shape
+    start = torch.randint(0, N, (B,), dtype=torch.long).to(xyz.device)
+    return ops.furthest_point_sample(xyz, npoint, start)
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """-> [B,S,nsample] int64, first nsample in-radius indices in ascending order (reference :97-112)."""
+    return ops.ball_query(radius, nsample, xyz, new_xyz)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points):
+    """FPS + ball query + grouping (reference :42-60).
+
+    xyz [B,N,3], points [B,N,C] or None -> new_xyz [B,S,3], new_points [B,S,nsample,3+C]
+    with the centred coordinates FIRST (:56)."""
+    fps_idx = farthest_point_sample(xyz, npoint)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    return new_xyz, ops.group_points(xyz, new_xyz, points, idx)
+
+
+# ---------------------------------------------------------------------------------------------
+# pointwise layers on channels-last rows, driven by the stock sub-modules' parameters
+# ---------------------------------------------------------------------------------------------
+def _conv_rows(conv, x):
+    """1x1 Conv1d/Conv2d as a row GEMM: x [rows, Cin] -> [rows, Cout]."""
+    w = conv.weight.view(conv.out_channels, conv.in_channels)
+    return F.linear(x, w, conv.bias)
+
+
+def _bn_rows(bn, x):
+    """BatchNorm1d/2d over rows [rows, C] with the module's exact running-stat bookkeeping."""
+    eaf = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        eaf = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    return F.batch_norm(
+        x,
+        bn.running_mean if (not bn.training or bn.track_running_stats) else None,
+        bn.running_var if (not bn.training or bn.track_running_stats) else None,
+        bn.weight, bn.bias, use_batch, eaf, bn.eps)
+
+
+def _mlp_rows(convs, bns, x):
+    for conv, bn in zip(convs, bns):
+        x = F.relu(_bn_rows(bn, _conv_rows(conv, x)))
+    return x
+
+
+def _channels_last(points):
+    """[B,C,N] (any strides) -> contiguous [B,N,C]; free when `points` came out of this module."""
+    return points.transpose(1, 2).contiguous()
+
+
+def _seq_rows(seq, x):
+    """Run an nn.Sequential of Conv1d / BatchNorm1d / ReLU / Sigmoid on rows."""
+    for m in seq:
+        if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+            x = _conv_rows(m, x)
+        elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            x = _bn_rows(m, x)
+        elif isinstance(m, nn.ReLU):
+            x = F.relu(x)
+        elif isinstance(m, nn.Sigmoid):
+            x = torch.sigmoid(x)
+        else:
+            raise TypeError(f"unsupported layer in pointwise stack: {type(m).__name__}")
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# modules (reference: pointnet2_utils.py:115-360)
+# ---------------------------------------------------------------------------------------------
+class SetAbstraction(nn.Module):
+    """Single-scale set abstraction (reference :115-156)."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        widths = [in_channel] + list(mlp)
+        for cin, cout in zip(widths[:-1], widths[1:]):
+            self.mlp_convs.append(nn.Conv2d(cin, cout, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(cout))
+
+    def forward(self, xyz, points):
+        """xyz [B,N,3], points [B,C,N] or None -> new_xyz [B,S,3], new_points [B,mlp[-1],S]."""
+        feat = None if points is None else _channels_last(points)
+        new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, feat)
+        B, S, ns, cin = grouped.shape
+        x = _mlp_rows(self.mlp_convs, self.mlp_bns, grouped.view(B * S * ns, cin))
+        x = x.view(B, S, ns, -1).max(dim=2)[0]
+        return new_xyz, x.transpose(1, 2)
+
+
+class MultiScaleSetAbstraction(nn.Module):
+    """Multi-scale grouping set abstraction (reference :302-360).  `in_channel` already counts the
+    3 centred coordinates (models/model.py:69,75-76)."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp):
+        super().__init__()
+        self.npoint = npoint
+        self.radius_list = radius_list
+        self.nsample_list = nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        widths = [in_channel] + list(mlp)
+        for _ in radius_list:
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            for cin, cout in zip(widths[:-1], widths[1:]):
+                convs.append(nn.Conv2d(cin, cout, 1))
+                bns.append(nn.BatchNorm2d(cout))
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+    def forward(self, xyz, points):
+        """xyz [B,N,3], points [B,C,N] or None -> new_xyz [B,S,3], [B, len(radius)*mlp[-1], S]."""
+        feat = None if points is None else _channels_last(points)
+        fps_idx = farthest_point_sample(xyz, self.npoint)  # one FPS for all scales (:335)
+        new_xyz = index_points(xyz, fps_idx)
+        if len(self.radius_list) == 2:
+            idx_list = ops.ball_query2(self.radius_list, self.nsample_list, xyz, new_xyz)
+        else:
+            idx_list = [query_ball_point(r, ns, xyz, new_xyz)
+                        for r, ns in zip(self.radius_list, self.nsample_list)]
+        outs = []
+        for i, idx in enumerate(idx_list):
+            grouped = ops.group_points(xyz, new_xyz, feat, idx)
+            B, S, ns, cin = grouped.shape
+            x = _mlp_rows(self.conv_blocks[i], self.bn_blocks[i], grouped.view(B * S * ns, cin))
+            outs.append(x.view(B, S, ns, -1).max(dim=2)[0])
+        return new_xyz, torch.cat(outs, dim=2).transpose(1, 2)
+
+
+def _interpolate(xyz1, xyz2, points2, k):
+    """points2 [B,D,S] at xyz2 -> [B,N,D] at xyz1 by inverse-distance weights of the k nearest."""
+    S = xyz2.shape[1]
+    if S == 1:
+        # The reference's S == 1 branch (:181-182 / :250-251) builds a [B,D,N] tensor where the
+        # following cat / conv need [B,N,D] and raises RuntimeError for every input; there is no
+        # reference result to reproduce, so this raises as well.
+        raise RuntimeError("feature propagation from a single centroid (S == 1) fails in the reference "
+                           "(shape mismatch in its repeat branch) and is not supported")
+    d2, idx = ops.three_nn(xyz1, xyz2, k)
+    return ops.three_interpolate(_channels_last(points2), d2, idx)
+
+
+class FeaturePropagation(nn.Module):
+    """3-NN inverse-distance feature propagation (reference :159-211)."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        widths = [in_channel] + list(mlp)
+        for cin, cout in zip(widths[:-1], widths[1:]):
+            self.mlp_convs.append(nn.Conv1d(cin, cout, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(cout))
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        """xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,D1,N] or None, points2 [B,D2,S] -> [B,mlp[-1],N]."""
+        B, N, _ = xyz1.shape
+        x = _interpolate(xyz1, xyz2, points2, 3)
+        if points1 is not None:
+            x = torch.cat([_channels_last(points1), x], dim=-1)  # skip features FIRST (:201)
+        x = _mlp_rows(self.mlp_convs, self.mlp_bns, x.reshape(B * N, -1))
+        return x.view(B, N, -1).transpose(1, 2)
+
+
+class EnhancedFeaturePropagation(nn.Module):
+    """4-NN propagation + channel attention + boundary term + residual (reference :214-298)."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        self.attention = nn.Sequential(
+            nn.Conv1d(in_channel, in_channel // 4, 1),
+            nn.BatchNorm1d(in_channel // 4),
+            nn.ReLU(),
+            nn.Conv1d(in_channel // 4, in_channel, 1),
+            nn.Sigmoid())
+        self.skip_connection = (in_channel == mlp[-1])
+        widths = [in_channel] + list(mlp)
+        for cin, cout in zip(widths[:-1], widths[1:]):
+            self.mlp_convs.append(nn.Conv1d(cin, cout, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(cout))
+        self.boundary_aware = nn.Sequential(
+            nn.Conv1d(3, 16, 1),
+            nn.BatchNorm1d(16),
+            nn.ReLU(),
+            nn.Conv1d(16, mlp[-1], 1))
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        B, N, _ = xyz1.shape
+        x = _interpolate(xyz1, xyz2, points2, 4)
+        if points1 is not None:
+            x = torch.cat([_channels_last(points1), x], dim=-1)
+        x = x.reshape(B * N, -1)
+        x = x * _seq_rows(self.attention, x)                       # :279-280
+        edge = _seq_rows(self.boundary_aware, xyz1.reshape(B * N, 3))  # :283
+        identity = x
+        x = _mlp_rows(self.mlp_convs, self.mlp_bns, x)
+        if self.skip_connection:
+            x = x + identity                                        # :292-293
+        x = x + edge                                                # :296
+        return x.view(B, N, -1).transpose(1, 2)

@@ -1,0 +1,321 @@
+"""Tensor-level operators over libpcb_hip.so.
+
+Index ops (no gradient): furthest_point_sample, ball_query, ball_query2, three_nn, knn.
+Differentiable ops (torch.autograd.Function): gather_rows, group_points, three_interpolate,
+edge_features.  The north_star names of the PointNet++ CUDA-extension lineage
+(furthest_point_sample, ball_query, group_points, three_nn, three_interpolate) do not exist as
+symbols in the reference; its Python compositions in Highway_bridge/models/pointnet2_utils.py and
+DGCNN.py define their semantics, and each function below cites the lines it replaces.
+
+Every op needs CUDA (ROCm) tensors and the built library; there is no CPU path.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "pointcloud_bridge_amd operators run on the GPU only (HIP kernels, no CPU fallback); "
+                f"got a tensor on {t.device}")
+    dev = tensors[0].device
+    for t in tensors:
+        if t is not None and t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _i64c(t, name):
+    if t.dtype != torch.int64:
+        raise TypeError(f"{name} must be int64 (torch.long), got {t.dtype}")
+    return t.contiguous()
+
+
+def _xyz(t, name):
+    if t.dim() != 3 or t.shape[-1] != 3:
+        raise ValueError(f"{name} must be [B,N,3], got {tuple(t.shape)}")
+    return _f32c(t, name)
+
+
+# --------------------------------------------------------------------------------------------
+# index ops
+# --------------------------------------------------------------------------------------------
+def square_distance(src, dst):
+    """Materialised pairwise squared distances (pointnet2_utils.py:7-14) -> [B,N,M] fp32."""
+    _need_cuda(src, dst)
+    src, dst = _xyz(src, "src"), _xyz(dst, "dst")
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    out = torch.empty(B, N, M, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().pcb_square_distance(src.data_ptr(), dst.data_ptr(), B, N, M, out.data_ptr(),
+                                                   _stream()), "pcb_square_distance")
+    return out
+
+
+def furthest_point_sample(xyz, npoint, start_idx):
+    """FPS, replaces pointnet2_utils.py:63-80.  start_idx [B] int64 = the reference's randint draw."""
+    _need_cuda(xyz, start_idx)
+    xyz = _xyz(xyz, "xyz")
+    start_idx = _i64c(start_idx, "start_idx")
+    B, N, _ = xyz.shape
+    if start_idx.shape != (B,):
+        raise ValueError(f"start_idx must be [B]={B}, got {tuple(start_idx.shape)}")
+    out = torch.empty(B, int(npoint), dtype=torch.int64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.load().pcb_fps(xyz.data_ptr(), B, N, int(npoint), start_idx.data_ptr(),
+                                       out.data_ptr(), _stream()), "pcb_fps")
+    return out
+
+
+def _r2(radius):
+    # python double square, one rounding to fp32: what ATen does with the scalar in
+    # `sqrdists > radius ** 2` (pointnet2_utils.py:105)
+    return float(torch.tensor(float(radius) ** 2, dtype=torch.float32).item())
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """Ball query, replaces pointnet2_utils.py:97-112 -> [B,S,nsample] int64."""
+    _need_cuda(xyz, new_xyz)
+    xyz, new_xyz = _xyz(xyz, "xyz"), _xyz(new_xyz, "new_xyz")
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    nsample = int(nsample)
+    if nsample > N:
+        # the reference fails here too (mask/tensor shape mismatch at pointnet2_utils.py:110)
+        raise IndexError(f"nsample ({nsample}) exceeds the number of points ({N})")
+    out = torch.empty(B, S, nsample, dtype=torch.int64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.load().pcb_ball_query(xyz.data_ptr(), new_xyz.data_ptr(), B, N, S, _r2(radius),
+                                              nsample, out.data_ptr(), _stream()), "pcb_ball_query")
+    return out
+
+
+def ball_query2(radii, nsamples, xyz, new_xyz):
+    """Two ball queries over the same centroids in one sweep (pointnet2_utils.py:340-341 twice)."""
+    _need_cuda(xyz, new_xyz)
+    xyz, new_xyz = _xyz(xyz, "xyz"), _xyz(new_xyz, "new_xyz")
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    (ra, rb), (na, nb) = radii, (int(nsamples[0]), int(nsamples[1]))
+    if max(na, nb) > N:
+        raise IndexError(f"nsample ({max(na, nb)}) exceeds the number of points ({N})")
+    oa = torch.empty(B, S, na, dtype=torch.int64, device=xyz.device)
+    ob = torch.empty(B, S, nb, dtype=torch.int64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.load().pcb_ball_query2(xyz.data_ptr(), new_xyz.data_ptr(), B, N, S,
+                                               _r2(ra), na, oa.data_ptr(), _r2(rb), nb, ob.data_ptr(),
+                                               _stream()), "pcb_ball_query2")
+    return oa, ob
+
+
+def three_nn(xyz1, xyz2, k=3):
+    """k nearest of xyz2 for each point of xyz1 (pointnet2_utils.py:185-188, :253-256).
+
+    Returns (d2 [B,N,k] fp32 ascending, idx [B,N,k] int64)."""
+    _need_cuda(xyz1, xyz2)
+    xyz1, xyz2 = _xyz(xyz1, "xyz1"), _xyz(xyz2, "xyz2")
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    if not 1 <= k <= 4 or S < k:
+        raise ValueError(f"three_nn needs 1 <= k <= 4 and S >= k (k={k}, S={S})")
+    d2 = torch.empty(B, N, k, dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty(B, N, k, dtype=torch.int64, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _lib.check(_lib.load().pcb_three_nn(xyz1.data_ptr(), xyz2.data_ptr(), B, N, S, k, d2.data_ptr(),
+                                            idx.data_ptr(), _stream()), "pcb_three_nn")
+    return d2, idx
+
+
+def knn(x_bnd, k):
+    """kNN graph on x [B,N,D] (DGCNN.py:49-70 after its transpose at :60) -> [B,N,k] int64."""
+    _need_cuda(x_bnd)
+    if x_bnd.dim() != 3:
+        raise ValueError(f"x must be [B,N,D], got {tuple(x_bnd.shape)}")
+    x = _f32c(x_bnd, "x")
+    B, N, D = x.shape
+    k = int(k)
+    if k > N:
+        raise RuntimeError(f"k ({k}) exceeds the number of points ({N})")  # torch.topk raises too
+    if not 1 <= k <= 32 or D > 128:
+        raise ValueError(f"knn supports 1 <= k <= 32 and D <= 128 (k={k}, D={D})")
+    out = torch.empty(B, N, k, dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().pcb_knn(x.data_ptr(), B, N, D, k, out.data_ptr(), _stream()), "pcb_knn")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# differentiable ops
+# --------------------------------------------------------------------------------------------
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx_flat):
+        B, N, C = points.shape
+        M = idx_flat.shape[1]
+        out = torch.empty(B, M, C, dtype=torch.float32, device=points.device)
+        with torch.cuda.device(points.device):
+            _lib.check(_lib.load().pcb_gather_rows(points.data_ptr(), idx_flat.data_ptr(), B, N, C, M,
+                                                   out.data_ptr(), _stream()), "pcb_gather_rows")
+        ctx.save_for_backward(idx_flat)
+        ctx.shape = (B, N, C, M)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx_flat,) = ctx.saved_tensors
+        B, N, C, M = ctx.shape
+        g = g.contiguous()
+        gp = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().pcb_gather_rows_bwd(g.data_ptr(), idx_flat.data_ptr(), B, N, C, M,
+                                                       gp.data_ptr(), _stream()), "pcb_gather_rows_bwd")
+        return gp, None
+
+
+def gather_rows(points, idx):
+    """index_points (pointnet2_utils.py:17-39): points [B,N,C] fp32, idx [B,...] int64 -> [B,...,C].
+
+    Indices are clamped to [0,N-1] like the reference (:34-36)."""
+    _need_cuda(points, idx)
+    if points.dim() != 3:
+        raise ValueError(f"points must be [B,N,C], got {tuple(points.shape)}")
+    points = _f32c(points, "points")
+    idx = _i64c(idx, "idx")
+    B = points.shape[0]
+    out = _GatherRows.apply(points, idx.reshape(B, -1))
+    return out.view(*idx.shape, points.shape[2])
+
+
+class _GroupPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feat, idx):
+        B, N, _ = xyz.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        C = 0 if feat is None else feat.shape[2]
+        out = torch.empty(B, S, ns, 3 + C, dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.check(_lib.load().pcb_group_points(
+                xyz.data_ptr(), new_xyz.data_ptr(), 0 if feat is None else feat.data_ptr(),
+                idx.data_ptr(), B, N, S, ns, C, out.data_ptr(), _stream()), "pcb_group_points")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, S, ns, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, S, ns, C = ctx.shape
+        if C == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None
+        g = g.contiguous()
+        gf = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().pcb_group_points_bwd(g.data_ptr(), idx.data_ptr(), B, N, S, ns, C,
+                                                        gf.data_ptr(), _stream()), "pcb_group_points_bwd")
+        return None, None, gf, None
+
+
+def group_points(xyz, new_xyz, feat, idx):
+    """cat(xyz[idx] - new_xyz, feat[idx]) -> [B,S,ns,3+C] (pointnet2_utils.py:51-58, :342-349).
+
+    feat is [B,N,C] fp32 or None.  Gradient flows to feat only: xyz is input data."""
+    _need_cuda(xyz, new_xyz, feat, idx)
+    xyz, new_xyz = _xyz(xyz, "xyz"), _xyz(new_xyz, "new_xyz")
+    idx = _i64c(idx, "idx")
+    if feat is not None:
+        feat = _f32c(feat, "feat")
+        if feat.shape[:2] != xyz.shape[:2]:
+            raise ValueError(f"feat {tuple(feat.shape)} does not match xyz {tuple(xyz.shape)}")
+    if idx.dim() != 3 or idx.shape[:2] != new_xyz.shape[:2]:
+        raise ValueError(f"idx must be [B,S,ns] matching new_xyz, got {tuple(idx.shape)}")
+    return _GroupPoints.apply(xyz, new_xyz, feat, idx)
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, d2, idx):
+        B, S, C = feat.shape
+        N, k = d2.shape[1], d2.shape[2]
+        out = torch.empty(B, N, C, dtype=torch.float32, device=feat.device)
+        w = torch.empty(B, N, k, dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _lib.check(_lib.load().pcb_interpolate(feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S,
+                                                   C, k, out.data_ptr(), w.data_ptr(), _stream()),
+                       "pcb_interpolate")
+        ctx.save_for_backward(w, idx)
+        ctx.shape = (B, N, S, C, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, idx = ctx.saved_tensors
+        B, N, S, C, k = ctx.shape
+        g = g.contiguous()
+        gf = torch.zeros(B, S, C, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().pcb_interpolate_bwd(g.data_ptr(), w.data_ptr(), idx.data_ptr(), B, N, S,
+                                                       C, k, gf.data_ptr(), _stream()),
+                       "pcb_interpolate_bwd")
+        return gf, None, None
+
+
+def three_interpolate(feat_bsc, d2, idx):
+    """Inverse-distance weighted sum of the k nearest rows (pointnet2_utils.py:191-196, :259-267).
+
+    feat [B,S,C], d2/idx [B,N,k] from three_nn -> [B,N,C].  Gradient flows to feat only."""
+    _need_cuda(feat_bsc, d2, idx)
+    feat = _f32c(feat_bsc, "feat")
+    d2 = _f32c(d2, "d2")
+    idx = _i64c(idx, "idx")
+    if d2.shape != idx.shape or d2.dim() != 3 or d2.shape[0] != feat.shape[0]:
+        raise ValueError(f"d2 {tuple(d2.shape)} / idx {tuple(idx.shape)} / feat {tuple(feat.shape)} mismatch")
+    return _ThreeInterpolate.apply(feat, d2, idx)
+
+
+class _EdgeFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        B, N, D = x.shape
+        k = idx.shape[2]
+        out = torch.empty(B, N, k, 2 * D, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().pcb_edge_features(x.data_ptr(), idx.data_ptr(), B, N, D, k,
+                                                     out.data_ptr(), _stream()), "pcb_edge_features")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, D, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, D, k = ctx.shape
+        g = g.contiguous()
+        gx = torch.zeros(B, N, D, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().pcb_edge_features_bwd(g.data_ptr(), idx.data_ptr(), B, N, D, k,
+                                                         gx.data_ptr(), _stream()), "pcb_edge_features_bwd")
+        return gx, None
+
+
+def edge_features(x_bnd, idx):
+    """EdgeConv input cat(x_j - x_i, x_i) -> [B,N,k,2D] (DGCNN.py:90-107, channels-last)."""
+    _need_cuda(x_bnd, idx)
+    x = _f32c(x_bnd, "x")
+    idx = _i64c(idx, "idx")
+    if x.dim() != 3 or idx.dim() != 3 or idx.shape[:2] != x.shape[:2]:
+        raise ValueError(f"x {tuple(x.shape)} / idx {tuple(idx.shape)} mismatch")
+    return _EdgeFeatures.apply(x, idx)
