@@ -71,6 +71,8 @@ def _conv_rows(conv, x):
 
 def _bn_rows(bn, x):
     """BatchNorm1d/2d over rows [rows, C] with the module's exact running-stat bookkeeping."""
+    if isinstance(bn, nn.SyncBatchNorm):
+        return bn(x)  # statistics all-reduced over the process group (parallel.sync_batchnorm)
     eaf = 0.0 if bn.momentum is None else bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)

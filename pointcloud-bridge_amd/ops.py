@@ -18,6 +18,43 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional live timing of ONE entry point (bench.py's roofline leg): HIP events are recorded on the
+# stream the kernel is launched on (torch's current stream) around every launch of that entry point.
+_timer = None
+
+
+def kernel_timer_start(name):
+    """Start recording (event pairs, work units) for every launch of C-ABI entry point `name`."""
+    global _timer
+    _timer = {"name": name, "events": [], "units": 0}
+
+
+def kernel_timer_stop():
+    """-> (launches, total milliseconds, total work units) since kernel_timer_start; synchronises."""
+    global _timer
+    t, _timer = _timer, None
+    if t is None:
+        return 0, 0.0, 0
+    torch.cuda.synchronize()
+    return len(t["events"]), sum(a.elapsed_time(b) for a, b in t["events"]), t["units"]
+
+
+def _launch(name, units, *args):
+    """Call entry point `name` of libpcb_hip.so on the current stream; raise on a bad status."""
+    fn = getattr(_lib.load(), name)
+    t = _timer
+    if t is not None and t["name"] == name:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        status = fn(*args, _stream())
+        b.record()
+        t["events"].append((a, b))
+        t["units"] += units
+    else:
+        status = fn(*args, _stream())
+    _lib.check(status, name)
+
+
 def _need_cuda(*tensors):
     for t in tensors:
         if t is None:
@@ -61,8 +98,7 @@ def square_distance(src, dst):
     M = dst.shape[1]
     out = torch.empty(B, N, M, dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):
-        _lib.check(_lib.load().pcb_square_distance(src.data_ptr(), dst.data_ptr(), B, N, M, out.data_ptr(),
-                                                   _stream()), "pcb_square_distance")
+        _launch("pcb_square_distance", B * N * M, src.data_ptr(), dst.data_ptr(), B, N, M, out.data_ptr())
     return out
 
 
@@ -76,8 +112,7 @@ def furthest_point_sample(xyz, npoint, start_idx):
         raise ValueError(f"start_idx must be [B]={B}, got {tuple(start_idx.shape)}")
     out = torch.empty(B, int(npoint), dtype=torch.int64, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _lib.check(_lib.load().pcb_fps(xyz.data_ptr(), B, N, int(npoint), start_idx.data_ptr(),
-                                       out.data_ptr(), _stream()), "pcb_fps")
+        _launch("pcb_fps", B * N * int(npoint), xyz.data_ptr(), B, N, int(npoint), start_idx.data_ptr(), out.data_ptr())
     return out
 
 
@@ -99,8 +134,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
         raise IndexError(f"nsample ({nsample}) exceeds the number of points ({N})")
     out = torch.empty(B, S, nsample, dtype=torch.int64, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _lib.check(_lib.load().pcb_ball_query(xyz.data_ptr(), new_xyz.data_ptr(), B, N, S, _r2(radius),
-                                              nsample, out.data_ptr(), _stream()), "pcb_ball_query")
+        _launch("pcb_ball_query", B * S * N, xyz.data_ptr(), new_xyz.data_ptr(), B, N, S, _r2(radius), nsample, out.data_ptr())
     return out
 
 
@@ -116,9 +150,7 @@ def ball_query2(radii, nsamples, xyz, new_xyz):
     oa = torch.empty(B, S, na, dtype=torch.int64, device=xyz.device)
     ob = torch.empty(B, S, nb, dtype=torch.int64, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _lib.check(_lib.load().pcb_ball_query2(xyz.data_ptr(), new_xyz.data_ptr(), B, N, S,
-                                               _r2(ra), na, oa.data_ptr(), _r2(rb), nb, ob.data_ptr(),
-                                               _stream()), "pcb_ball_query2")
+        _launch("pcb_ball_query2", B * S * N, xyz.data_ptr(), new_xyz.data_ptr(), B, N, S, _r2(ra), na, oa.data_ptr(), _r2(rb), nb, ob.data_ptr())
     return oa, ob
 
 
@@ -135,8 +167,7 @@ def three_nn(xyz1, xyz2, k=3):
     d2 = torch.empty(B, N, k, dtype=torch.float32, device=xyz1.device)
     idx = torch.empty(B, N, k, dtype=torch.int64, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
-        _lib.check(_lib.load().pcb_three_nn(xyz1.data_ptr(), xyz2.data_ptr(), B, N, S, k, d2.data_ptr(),
-                                            idx.data_ptr(), _stream()), "pcb_three_nn")
+        _launch("pcb_three_nn", B * N * S, xyz1.data_ptr(), xyz2.data_ptr(), B, N, S, k, d2.data_ptr(), idx.data_ptr())
     return d2, idx
 
 
@@ -154,7 +185,7 @@ def knn(x_bnd, k):
         raise ValueError(f"knn supports 1 <= k <= 32 and D <= 128 (k={k}, D={D})")
     out = torch.empty(B, N, k, dtype=torch.int64, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().pcb_knn(x.data_ptr(), B, N, D, k, out.data_ptr(), _stream()), "pcb_knn")
+        _launch("pcb_knn", B * N * N, x.data_ptr(), B, N, D, k, out.data_ptr())
     return out
 
 
@@ -168,8 +199,7 @@ class _GatherRows(torch.autograd.Function):
         M = idx_flat.shape[1]
         out = torch.empty(B, M, C, dtype=torch.float32, device=points.device)
         with torch.cuda.device(points.device):
-            _lib.check(_lib.load().pcb_gather_rows(points.data_ptr(), idx_flat.data_ptr(), B, N, C, M,
-                                                   out.data_ptr(), _stream()), "pcb_gather_rows")
+            _launch("pcb_gather_rows", B * M * C, points.data_ptr(), idx_flat.data_ptr(), B, N, C, M, out.data_ptr())
         ctx.save_for_backward(idx_flat)
         ctx.shape = (B, N, C, M)
         return out
@@ -181,8 +211,7 @@ class _GatherRows(torch.autograd.Function):
         g = g.contiguous()
         gp = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.check(_lib.load().pcb_gather_rows_bwd(g.data_ptr(), idx_flat.data_ptr(), B, N, C, M,
-                                                       gp.data_ptr(), _stream()), "pcb_gather_rows_bwd")
+            _launch("pcb_gather_rows_bwd", B * M * C, g.data_ptr(), idx_flat.data_ptr(), B, N, C, M, gp.data_ptr())
         return gp, None
 
 
@@ -208,9 +237,7 @@ class _GroupPoints(torch.autograd.Function):
         C = 0 if feat is None else feat.shape[2]
         out = torch.empty(B, S, ns, 3 + C, dtype=torch.float32, device=xyz.device)
         with torch.cuda.device(xyz.device):
-            _lib.check(_lib.load().pcb_group_points(
-                xyz.data_ptr(), new_xyz.data_ptr(), 0 if feat is None else feat.data_ptr(),
-                idx.data_ptr(), B, N, S, ns, C, out.data_ptr(), _stream()), "pcb_group_points")
+            _launch("pcb_group_points", B * S * ns * (3 + C),  xyz.data_ptr(), new_xyz.data_ptr(), 0 if feat is None else feat.data_ptr(), idx.data_ptr(), B, N, S, ns, C, out.data_ptr())
         ctx.save_for_backward(idx)
         ctx.shape = (B, N, S, ns, C)
         return out
@@ -224,8 +251,7 @@ class _GroupPoints(torch.autograd.Function):
         g = g.contiguous()
         gf = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.check(_lib.load().pcb_group_points_bwd(g.data_ptr(), idx.data_ptr(), B, N, S, ns, C,
-                                                        gf.data_ptr(), _stream()), "pcb_group_points_bwd")
+            _launch("pcb_group_points_bwd", B * S * ns * C, g.data_ptr(), idx.data_ptr(), B, N, S, ns, C, gf.data_ptr())
         return None, None, gf, None
 
 
@@ -253,9 +279,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         out = torch.empty(B, N, C, dtype=torch.float32, device=feat.device)
         w = torch.empty(B, N, k, dtype=torch.float32, device=feat.device)
         with torch.cuda.device(feat.device):
-            _lib.check(_lib.load().pcb_interpolate(feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S,
-                                                   C, k, out.data_ptr(), w.data_ptr(), _stream()),
-                       "pcb_interpolate")
+            _launch("pcb_interpolate", B * N * C, feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S, C, k, out.data_ptr(), w.data_ptr())
         ctx.save_for_backward(w, idx)
         ctx.shape = (B, N, S, C, k)
         return out
@@ -267,9 +291,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         g = g.contiguous()
         gf = torch.zeros(B, S, C, dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.check(_lib.load().pcb_interpolate_bwd(g.data_ptr(), w.data_ptr(), idx.data_ptr(), B, N, S,
-                                                       C, k, gf.data_ptr(), _stream()),
-                       "pcb_interpolate_bwd")
+            _launch("pcb_interpolate_bwd", B * N * C, g.data_ptr(), w.data_ptr(), idx.data_ptr(), B, N, S, C, k, gf.data_ptr())
         return gf, None, None
 
 
@@ -293,8 +315,7 @@ class _EdgeFeatures(torch.autograd.Function):
         k = idx.shape[2]
         out = torch.empty(B, N, k, 2 * D, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.load().pcb_edge_features(x.data_ptr(), idx.data_ptr(), B, N, D, k,
-                                                     out.data_ptr(), _stream()), "pcb_edge_features")
+            _launch("pcb_edge_features", B * N * k * 2 * D, x.data_ptr(), idx.data_ptr(), B, N, D, k, out.data_ptr())
         ctx.save_for_backward(idx)
         ctx.shape = (B, N, D, k)
         return out
@@ -306,8 +327,7 @@ class _EdgeFeatures(torch.autograd.Function):
         g = g.contiguous()
         gx = torch.zeros(B, N, D, dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.check(_lib.load().pcb_edge_features_bwd(g.data_ptr(), idx.data_ptr(), B, N, D, k,
-                                                         gx.data_ptr(), _stream()), "pcb_edge_features_bwd")
+            _launch("pcb_edge_features_bwd", B * N * k * 2 * D, g.data_ptr(), idx.data_ptr(), B, N, D, k, gx.data_ptr())
         return gx, None
 
 

