@@ -1,0 +1,74 @@
+"""CPU, world_size 2 over gloo: the data-parallel pieces of the N>1 path (scene sharding, parameter
+broadcast, single flat gradient all-reduce).  The HIP operators are per-scene and need no
+collective; what is covered here is everything the multi-GPU bench adds around them."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pointcloud_bridge_amd import parallel
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+
+    torch.manual_seed(100 + rank)  # deliberately different init per rank
+    model = nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.ReLU(), nn.Linear(8, 3))
+    parallel.broadcast_parameters(model)
+    ref = [p.detach().clone() for p in model.parameters()]
+    gathered = [torch.zeros_like(ref[0]) for _ in range(world)]
+    dist.all_gather(gathered, ref[0])
+    assert all(torch.equal(g, gathered[0]) for g in gathered)  # every rank holds rank 0's weights
+
+    # global batch of 8 "scenes", sharded; mean gradient over shards == full-batch gradient / 1
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    mine = list(parallel.shard_scenes(8, rank, world))
+    assert len(mine) == 4 and mine[0] == rank * 4
+    model.eval()  # no batch statistics: the sharded mean must equal the single-process gradient
+    bucket = parallel.FlatGradAllReduce(model.parameters())
+    bucket.zero()
+    ((model(X[mine]) - Y[mine]) ** 2).mean().backward()
+    bucket.reduce()
+    got = [p.grad.clone() for p in model.parameters()]
+
+    full = nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.ReLU(), nn.Linear(8, 3)).eval()
+    full.load_state_dict(model.state_dict())
+    ((full(X) - Y) ** 2).mean().backward()
+    for a, p in zip(got, full.parameters()):
+        torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-6)
+    # gradients live inside the flat bucket (no pack/unpack copies)
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in model.parameters())
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_flat_grad_allreduce_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_shard_scenes_covers_every_scene_once():
+    from pointcloud_bridge_amd import parallel
+    for n in (16, 17, 5, 1):
+        for w in (1, 2, 3, 8):
+            seen = [i for r in range(w) for i in parallel.shard_scenes(n, r, w)]
+            assert seen == list(range(n))

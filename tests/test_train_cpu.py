@@ -1,0 +1,37 @@
+"""CPU: host-side pieces of the training harness (metrics as inference.py:814-855 defines them)."""
+import torch
+
+from pointcloud_bridge_amd import train
+
+
+def test_confusion_and_miou_match_definition():
+    target = torch.tensor([[0, 0, 1, 1, 2, 2, 2, 4]])
+    pred = torch.tensor([[0, 1, 1, 1, 2, 2, 0, 4]])
+    cm = train.confusion_matrix(pred, target, 5)
+    assert cm.tolist() == [[1, 1, 0, 0, 0], [0, 2, 0, 0, 0], [1, 0, 2, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 1]]
+    m = train.metrics_from_confusion(cm)
+    # per-point loop of the reference (inference.py:226-231) gives the same matrix
+    ref = torch.zeros(5, 5, dtype=torch.long)
+    for t, p in zip(target.view(-1), pred.view(-1)):
+        ref[t, p] += 1
+    assert torch.equal(ref, cm)
+    iou = [1 / 3, 2 / 3, 2 / 3, 0.0, 1.0]
+    assert all(abs(a - b) < 1e-5 for a, b in zip(m["iou"], iou))
+    assert abs(m["miou"] - (1 / 3 + 2 / 3 + 2 / 3 + 1.0) / 4) < 1e-5   # absent class 3 is skipped (nanmean)
+    assert abs(m["oa"] - 6 / 8) < 1e-9
+
+
+def test_losses_for_both_logit_layouts():
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(2, 5, 7, generator=g)
+    labels = torch.randint(0, 5, (2, 7), generator=g)
+    a = train.segmentation_loss(logits, labels)
+    b = train.segmentation_loss(logits.transpose(1, 2).contiguous(), labels, channels_last=True)
+    assert abs(float(a) - float(b)) < 1e-6
+    assert torch.equal(train.predictions(logits), train.predictions(logits.transpose(1, 2), channels_last=True))
+
+
+def test_synthetic_scenes_are_normalised_like_the_dataset():
+    b = train.synthetic_scenes(3, 500, seed=1)
+    assert b["points"].shape == (3, 500, 3) and b["labels"].max() <= 4
+    assert torch.allclose(b["points"].norm(dim=-1).max(dim=1)[0], torch.ones(3), atol=1e-5)

@@ -1,6 +1,6 @@
 import sys, time, faulthandler, torch
 faulthandler.dump_traceback_later(100, repeat=True, file=sys.stderr)
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from pointcloud_bridge_amd import ops
 t0 = time.time()

@@ -1,6 +1,6 @@
 """Scratch timing of the individual HIP operators at BASELINE sizes (not part of the product)."""
 import sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pointcloud_bridge_amd import ops
 
 def timeit(f, n=10, w=3):
