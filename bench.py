@@ -98,10 +98,13 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default 16; dgcnn 8)")
     ap.add_argument("--npoints", type=int, default=None, help="points per scene (default 16384; dgcnn 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks")
+    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (fp32 mode)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="pointwise-MLP arithmetic: bf16 activations (BASELINE config 2) or the fp32 parity mode")
     args = ap.parse_args()
 
-    from pointcloud_bridge_amd import ops, parallel
+    from pointcloud_bridge_amd import ops, parallel, rowmlp
+    rowmlp.set_precision(args.precision)
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -165,7 +168,7 @@ def main():
             "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} fwd+CE+bwd+grad-allreduce+Adam, B={B} scenes/GPU x N={N} pts, "
                                    f"unit-ball clouds (configs[1] of BASELINE.json)",
                        "scenes_per_gpu": B, "points_per_scene": N, "parallelism": f"dp{world} (scenes sharded)",

@@ -163,6 +163,124 @@ int pcb_edge_features(const float *x, const int64_t *idx, int B, int N, int D, i
 int pcb_edge_features_bwd(const float *grad_out, const int64_t *idx, int B, int N, int D, int k,
                           float *grad_x, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * bf16 channels-last row kernels around the pointwise-MLP GEMMs (csrc/rowbn.hip).
+ * They replace, per layer, the ATen passes behind Conv(1x1) -> BatchNorm -> ReLU/LeakyReLU
+ * [-> max over neighbours] in SetAbstraction.forward (models/pointnet2_utils.py:149-154),
+ * MultiScaleSetAbstraction.forward (:353-356), FeaturePropagation.forward (:207-209) and the
+ * EdgeConv blocks of DGCNN.forward (models/DGCNN.py:134-148).
+ * Activations are bf16 rows [rows, C] (C % 8 == 0, C <= 2048); statistics, scale/shift and
+ * gradients of the affine parameters are fp32.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).
+ */
+
+/* sums[0][c] += sum_r y[r][c]; sums[1][c] += sum_r y[r][c]^2.  sums [2,C] fp32, zeroed by the caller. */
+int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream);
+
+/*
+ * BatchNorm bookkeeping of one layer: scale = gamma*invstd, shift = beta - mean*scale.
+ * training != 0: batch statistics from sums/rows, running_mean/var updated with `momentum`
+ * (unbiased variance), `bias` (the conv bias the GEMM leaves out because it cancels inside a
+ * train-mode BatchNorm) added to the mean that enters running_mean.  training == 0: running
+ * statistics, bias folded into shift.  gamma/beta/bias/running_* may be NULL where unused.
+ * mean/invstd [C] are outputs for the backward pass.
+ */
+int pcb_bn_finalize(const float *sums, long rows, int C, const float *gamma, const float *beta,
+                    const float *bias, float *running_mean, float *running_var, float momentum,
+                    float eps, int training, float *scale, float *shift, float *mean, float *invstd,
+                    void *stream);
+
+/* z = act(y*scale + shift), y/z [rows,C] bf16. */
+int pcb_bn_act_bf16(const void *y, const float *scale, const float *shift, long rows, int C, int act,
+                    void *z, void *stream);
+
+/*
+ * Pooled form (torch.max over the neighbour axis, pointnet2_utils.py:154 / :356, DGCNN.py:136):
+ * out[g][c] = max_j act(y[g*ns+j][c]*scale+shift), argmax[g][c] = first j attaining it (uint8).
+ * y [groups*ns, C] bf16, out [groups, C] bf16, 1 <= ns <= 255.
+ */
+int pcb_bn_act_max_bf16(const void *y, const float *scale, const float *shift, long groups, int ns,
+                        int C, int act, void *out, unsigned char *argmax, void *stream);
+
+/*
+ * Backward of act(BatchNorm(y)) for a dense upstream gradient dz [rows,C] bf16:
+ * sums (zeroed by the caller) returns (sum du, sum du*xhat) = (dbeta, dgamma);
+ * dy = scale*(du - s1/rows - xhat*s2/rows) if use_batch_stats else scale*du.  dy [rows,C] bf16.
+ */
+int pcb_bn_act_bwd_bf16(const void *dz, const void *y, const float *scale, const float *shift,
+                        const float *mean, const float *invstd, long rows, int C, int act,
+                        int use_batch_stats, float *sums, void *dy, void *stream);
+
+/* Same for the pooled form: dout [groups,C] fp32 reaches only the arg-max rows; dy [groups*ns,C] bf16. */
+int pcb_bn_act_max_bwd_bf16(const float *dout, const unsigned char *argmax, const void *y,
+                            const float *scale, const float *shift, const float *mean,
+                            const float *invstd, long groups, int ns, int C, int act,
+                            int use_batch_stats, float *sums, void *dy, void *stream);
+
+/*
+ * Grouping straight into bf16 GEMM rows (sample_and_group / MSG grouping, pointnet2_utils.py:51-58,
+ * :342-349): out[(b,s,j)] = [feat[b,idx] (C) | xyz[b,idx]-new_xyz[b,s] (3) | 0 ... Kp).
+ * Features come FIRST here (16-byte chunks stay aligned); the caller permutes the weight columns.
+ * feat [B,N,C] bf16 or NULL, out [B*S*ns, Kp] bf16, Kp % 8 == 0, Kp >= C+3.
+ */
+int pcb_group_rows_bf16(const float *xyz, const float *new_xyz, const void *feat, const int64_t *idx,
+                        int B, int N, int S, int ns, int C, int Kp, void *out, void *stream);
+
+/* grad_feat[b,idx,c] += grad_rows[row][c] (c < C); grad_feat [B,N,C] fp32 zeroed by the caller. */
+int pcb_group_rows_bf16_bwd(const void *grad_rows, const int64_t *idx, int B, int N, int S, int ns,
+                            int C, int Kp, float *grad_feat, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bf16 MFMA row GEMMs with the neighbouring BatchNorm/activation algebra fused into operand loads
+ * and epilogues (csrc/gemm.hip).  Together with pcb_bn_finalize / pcb_bn_act_max_bf16 they are the
+ * whole Conv(1x1) -> BatchNorm -> activation stack of models/pointnet2_utils.py:149-154, :207-209,
+ * :353-356 and models/DGCNN.py:134-148: a layer stores only y = x W^T (bf16 rows).
+ *
+ * A-operand prologue `pro`:
+ *   0  plain rows a0 [R,K]
+ *   1  act(a0*scale + shift)                     (previous layer's BatchNorm + activation)
+ *   2  dy = scale*dz*act'(y*scale+shift) + p*y + q    with dz = a0, y = a1 (BatchNorm backward)
+ *   3  the same with dz[r][c] = (r % ns == argmax[r/ns][c]) ? dout[r/ns][c] : 0  (max-pooled layer)
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  scale/shift/p/q are fp32 [K].
+ */
+
+/* out[R,N] (bf16) = A'[R,K] . w[N,K]^T, fp32 accumulation.  If sums != NULL, sums[0][n] and
+ * sums[1][n] (fp32 [2,N], zeroed by the caller) receive the column sums / sums of squares of the
+ * rounded outputs.  N % 8 == 0, K % 8 == 0. */
+int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale, const float *shift,
+                     const float *p, const float *q, const float *dout, const unsigned char *argmax,
+                     int ns, int act, const void *w, long R, int N, int K, void *out, float *sums,
+                     void *stream);
+
+/* dW[M,N] (fp32, overwritten) = A'[R,M]^T . B'[R,N].
+ * A' = dz [R,M] itself (apro 0) or dy (apro 2 or 3, as above, built from dz|dout+argmax and y [R,M]);
+ * B' = x [R,N] (bpro 0) or act(x*xscale + xshift) (bpro 1).  M % 8 == 0, N % 8 == 0.
+ * The rows are split over workgroups; each split stores its partial tile into `workspace`
+ * (pcb_gemm_tn_workspace(R,M,N) floats, caller-owned) and a second kernel sums the slabs in a fixed
+ * order, so the result is bitwise reproducible (no atomics). */
+int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const float *scale, const float *shift,
+                     const float *p, const float *q, const float *dout, const unsigned char *argmax,
+                     int ns, int act, int bpro, const void *x, const float *xscale, const float *xshift,
+                     int xact, long R, int M, int N, float *workspace, float *dW, void *stream);
+
+/* Number of fp32 elements pcb_gemm_tn_bf16 needs in `workspace` for these sizes. */
+long pcb_gemm_tn_workspace(long R, int M, int N);
+
+/* p, q of the fused BatchNorm backward from sums = (sum du, sum du*xhat):
+ * p = -scale*invstd*s2/rows, q = -scale*s1/rows - p*mean; zeros when use_batch_stats == 0. */
+int pcb_bn_bwd_finalize(const float *sums, long rows, int C, const float *scale, const float *mean,
+                        const float *invstd, int use_batch_stats, float *p, float *q, void *stream);
+
+/* Backward sums only (no dy written): sums += (sum du, sum du*xhat) for a dense dz ... */
+int pcb_bn_act_bwd_reduce_bf16(const void *dz, const void *y, const float *scale, const float *shift,
+                               const float *mean, const float *invstd, long rows, int C, int act,
+                               float *sums, void *stream);
+
+/* ... and for a max-pooled layer (dout [groups,C] fp32, argmax [groups,C] uint8). */
+int pcb_bn_act_max_bwd_reduce_bf16(const float *dout, const unsigned char *argmax, const void *y,
+                                   const float *scale, const float *shift, const float *mean,
+                                   const float *invstd, long groups, int ns, int C, int act, float *sums,
+                                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,7 +169,10 @@ def pointnet2_msg(model, xyz, colors):
     l2 = _fp(model.fp3, l2_xyz, l3_xyz, l2, l3)
     l1 = _fp(model.fp2, l1_xyz, l2_xyz, l1, l2)
     l0 = _fp(model.fp1, xyz, l1_xyz, pts, l1)
-    return model.final_fusion(model.fusion([l2, l1, l0]))
+    n = l0.shape[2]
+    # MultiScaleFeatureFusion.forward, models/model.py:160-167: nearest resampling to N, conv each, cat
+    fused = torch.cat([conv(F.interpolate(f, size=n)) for f, conv in zip([l2, l1, l0], model.fusion.convs)], dim=1)
+    return model.final_fusion(fused)
 
 
 def graph_feature(x_bdn, k):

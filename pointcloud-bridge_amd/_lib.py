@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libpcb_hip.so")
 _p = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
+_l = ctypes.c_long
 
 # name -> argtypes, exactly the declarations of include/pcb_hip.h
 SIGNATURES = {
@@ -27,6 +28,20 @@ SIGNATURES = {
     "pcb_knn": [_p, _i, _i, _i, _i, _p, _p],
     "pcb_edge_features": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_edge_features_bwd": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "pcb_colstats_bf16": [_p, _l, _i, _p, _p],
+    "pcb_bn_finalize": [_p, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p],
+    "pcb_bn_act_bf16": [_p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_bn_act_max_bf16": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
+    "pcb_bn_act_bwd_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
+    "pcb_bn_act_max_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_group_rows_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_group_rows_bf16_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_gemm_nt_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p],
+    "pcb_gemm_tn_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _p],
+    "pcb_gemm_tn_workspace": [_l, _i, _i],
+    "pcb_bn_bwd_finalize": [_p, _l, _i, _p, _p, _p, _i, _p, _p, _p],
+    "pcb_bn_act_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
 }
 
 _lib = None
@@ -49,7 +64,8 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the build lacks a declared symbol
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_char_p if name == "pcb_status_string" else ctypes.c_int
+            fn.restype = (ctypes.c_char_p if name == "pcb_status_string"
+                          else ctypes.c_long if name == "pcb_gemm_tn_workspace" else ctypes.c_int)
         _lib = lib
     return _lib
 

@@ -1,0 +1,569 @@
+// bf16 MFMA row GEMMs of the shared pointwise MLPs for gfx950, with the BatchNorm / activation
+// algebra of the neighbouring layers fused into operand loads and epilogues.
+//
+// Reference composition per layer (models/pointnet2_utils.py:149-151, :207-209, :353-354;
+// models/DGCNN.py:19-30): Conv(1x1) -> BatchNorm -> ReLU/LeakyReLU on fp32 [B,C,S,ns] tensors,
+// i.e. one GEMM plus 5-7 elementwise/reduction passes, and the same again in backward.
+// Here a layer keeps only y = x W^T (bf16 rows).  Everything else is recomputed on the fly:
+//
+//   gemm_nt  out[R,N] = A'[R,K] . B[N,K]^T          (forward and input-gradient GEMM)
+//       A' = A                                   plain rows (grouped input)
+//          | act(A*scale + shift)                previous layer's BatchNorm+activation on load
+//          | dy(dz, y)                           BatchNorm/activation BACKWARD on load (dense dz)
+//          | dy(dout, argmax, y)                 the same for a max-pooled layer
+//       epilogue: bf16 store; optionally per-column sum / sum of squares (next BatchNorm's
+//       batch statistics) accumulated from the rounded outputs
+//   gemm_tn  dW[M,N] += A'[R,M]^T . B'[R,N]        (weight gradient, reduction over rows, fp32 atomics)
+//       A' = dy(...) as above, B' = plain rows | act(B*scale + shift)
+//
+// dy = scale*du + p*y + q with du = dz*act'(y*scale+shift); p, q fold the batch-statistics terms
+// (-s1/R - xhat*s2/R) and come from pcb_bn_bwd_finalize.
+//
+// These GEMMs are skinny (K, N <= a few hundred, R up to ~10^6): HBM-bound, so the design goal is
+// one coalesced pass over each activation with full 128-byte rows staged through LDS, fp32
+// accumulation in v_mfma_f32_32x32x16_bf16, and no intermediate tensor.  gemm_tn needs both
+// operands transposed (reduction index = row = slow memory axis): tiles are stored row-major as
+// loaded and read back with ds_read_b64_tr_b16 (hardware transpose read).
+#include "pcb_common.h"
+
+namespace {
+
+typedef unsigned short u16;
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ void unpack8(const uint4 &v, float *f)
+{
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float *f)
+{
+    uint4 v;
+    v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+    v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    return v;
+}
+__device__ __forceinline__ float act_fwd(float u, int act)
+{
+    return act == 1 ? fmaxf(u, 0.0f) : (act == 2 ? (u > 0.0f ? u : 0.2f * u) : u);
+}
+__device__ __forceinline__ float act_grad(float u, int act)
+{
+    return act == 1 ? (u > 0.0f ? 1.0f : 0.0f) : (act == 2 ? (u > 0.0f ? 1.0f : 0.2f) : 1.0f);
+}
+
+// ---- operand prologues ------------------------------------------------------------------------
+enum { PRO_PLAIN = 0, PRO_BNACT = 1, PRO_DY = 2, PRO_DY_POOL = 3 };
+
+struct Operand {
+    const u16 *a0;            // PLAIN/BNACT: the rows; DY: dz rows; DY_POOL: unused
+    const u16 *a1;            // DY / DY_POOL: y rows
+    long ld;                  // row stride in elements (same for a0 and a1)
+    const float *scale, *shift, *p, *q;   // per column
+    const float *dout;        // DY_POOL: [groups, cols] fp32
+    const unsigned char *arg; // DY_POOL: [groups, cols] uint8
+    int ns;                   // DY_POOL: rows per group
+    int act;
+};
+
+// Kernel-argument structs live in the kernarg segment; taking a reference to one makes the compiler
+// copy it to scratch.  A field-by-field copy into a local lets it dissolve into SGPRs instead.
+__device__ __forceinline__ Operand local_copy(const Operand &k)
+{
+    Operand o;
+    o.a0 = k.a0; o.a1 = k.a1; o.ld = k.ld;
+    o.scale = k.scale; o.shift = k.shift; o.p = k.p; o.q = k.q;
+    o.dout = k.dout; o.arg = k.arg; o.ns = k.ns; o.act = k.act;
+    return o;
+}
+
+// An operand chunk = 8 consecutive columns [c, c+8) of one row.  Loading is split in two so that a
+// stage's global loads can be in flight while the previous stage's MFMAs run:
+//   Raw<PRO>     the untransformed bytes of a chunk (issued early, no dependent math)
+//   Consts<PRO>  the per-column fp32 constants of the chunk's 8 columns
+//   finish()     the prologue math, producing the 8 packed bf16 values that go to LDS
+template <int PRO>
+struct Consts {
+    float scale[8], shift[8], p[8], q[8];
+    __device__ __forceinline__ void load(const Operand &o, int c, int cols)
+    {
+        if (PRO == PRO_PLAIN) return;
+        const bool ok = c < cols;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            scale[i] = ok ? o.scale[c + i] : 0.0f;
+            shift[i] = ok ? o.shift[c + i] : 0.0f;
+            if (PRO >= PRO_DY) {
+                p[i] = ok ? o.p[c + i] : 0.0f;
+                q[i] = ok ? o.q[c + i] : 0.0f;
+            }
+        }
+    }
+};
+
+template <int PRO>
+struct Raw {
+    uint4 v0;                 // PLAIN/BNACT: rows; DY: dz
+    uint4 v1;                 // DY / DY_POOL: y
+    float4 d0, d1;            // DY_POOL: dout
+    unsigned long long arg;   // DY_POOL: packed arg-max bytes
+    int j;                    // DY_POOL: row index inside its group
+    bool live;
+    __device__ __forceinline__ void load(const Operand &o, long r, int c, long rows, int cols)
+    {
+        // Loads are unconditional (from a clamped, always valid address) so that they stay plain
+        // register loads; out-of-range chunks are zeroed in finish().
+        live = r < rows && c < cols;
+        const long rs = r < rows ? r : rows - 1;
+        const int cs = c < cols ? c : 0;
+        if (PRO != PRO_DY_POOL) v0 = *reinterpret_cast<const uint4 *>(o.a0 + rs * o.ld + cs);
+        if (PRO >= PRO_DY) v1 = *reinterpret_cast<const uint4 *>(o.a1 + rs * o.ld + cs);
+        if (PRO == PRO_DY_POOL) {
+            const long g = rs / o.ns;
+            j = (int)(rs - g * o.ns);
+            arg = *reinterpret_cast<const unsigned long long *>(o.arg + g * cols + cs);
+            d0 = *reinterpret_cast<const float4 *>(o.dout + g * cols + cs);
+            d1 = *reinterpret_cast<const float4 *>(o.dout + g * cols + cs + 4);
+        }
+    }
+    __device__ __forceinline__ uint4 finish(const Consts<PRO> &k, int act) const
+    {
+        const uint32_t keep = live ? 0xffffffffu : 0u;
+        if (PRO == PRO_PLAIN) return make_uint4(v0.x & keep, v0.y & keep, v0.z & keep, v0.w & keep);
+        float f[8];
+        if (PRO == PRO_BNACT) {
+            unpack8(v0, f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = act_fwd(fmaf(f[i], k.scale[i], k.shift[i]), act);
+            const uint4 r = pack8(f);
+            return make_uint4(r.x & keep, r.y & keep, r.z & keep, r.w & keep);
+        }
+        float y[8];
+        unpack8(v1, y);
+        if (PRO == PRO_DY) {
+            unpack8(v0, f);
+        } else {
+            const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = ((int)((arg >> (8 * i)) & 0xff) == j) ? d[i] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float du = f[i] * act_grad(fmaf(y[i], k.scale[i], k.shift[i]), act);
+            f[i] = fmaf(k.scale[i], du, fmaf(k.p[i], y[i], k.q[i]));
+        }
+        const uint4 r = pack8(f);
+        return make_uint4(r.x & keep, r.y & keep, r.z & keep, r.w & keep);
+    }
+};
+
+// ---- gemm_nt ----------------------------------------------------------------------------------
+constexpr int NT_BM = 128, NT_BN = 128, NT_BK = 64;
+constexpr int NT_LD = NT_BK + 8;  // LDS row stride in bf16 (144 B): conflict-free ds_read_b128
+
+template <int PRO, int STATS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
+                                                       int N, int K, u16 *__restrict__ out,
+                                                       float *__restrict__ sums)
+{
+    const Operand A = local_copy(A_arg);
+    __shared__ __attribute__((aligned(16))) u16 As[NT_BM * NT_LD];
+    __shared__ __attribute__((aligned(16))) u16 Bs[NT_BN * NT_LD];
+    __shared__ float ssum[2 * NT_BN];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int n0 = blockIdx.y * NT_BN;
+    const int chunk = t & 7;   // 8-column chunk inside a BK stage
+    const int rrow = t >> 3;   // 0..31
+    const long tiles_m = (R + NT_BM - 1) / NT_BM;
+
+    // Persistent over row tiles: K is short (a few stages), so a workgroup that handled one tile
+    // would spend its life in load latency.  The (tile, k-stage) pairs of all its tiles form one
+    // stream of stages and the next stage's loads are always in flight under the current MFMAs,
+    // across tile boundaries too.
+    long tile = blockIdx.x;
+    if (tile >= tiles_m) return;
+    int k0 = 0;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    if (STATS) {
+        for (int i = t; i < 2 * NT_BN; i += 256) ssum[i] = 0.0f;
+    }
+
+    Raw<PRO> ra[4];
+    Consts<PRO> ka;
+    uint4 rb[4];
+    auto fetch = [&](long tl, int kb) {
+        const int kc = kb + chunk * 8;
+        const long mb = tl * NT_BM;
+        ka.load(A, kc, K);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i].load(A, mb + rrow + 32 * i, kc, R, K);
+            const int n = n0 + rrow + 32 * i;
+            const uint4 w = *reinterpret_cast<const uint4 *>(Bw + (long)(n < N ? n : N - 1) * K + (kc < K ? kc : 0));
+            const uint32_t keep = (n < N && kc < K) ? 0xffffffffu : 0u;
+            rb[i] = make_uint4(w.x & keep, w.y & keep, w.z & keep, w.w & keep);
+        }
+    };
+    fetch(tile, 0);
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4 *>(&As[(rrow + 32 * i) * NT_LD + chunk * 8]) = ra[i].finish(ka, A.act);
+            *reinterpret_cast<uint4 *>(&Bs[(rrow + 32 * i) * NT_LD + chunk * 8]) = rb[i];
+        }
+        __syncthreads();
+        int nk = k0 + NT_BK;
+        long ntile = tile;
+        if (nk >= K) {
+            nk = 0;
+            ntile += gridDim.x;
+        }
+        const bool more = ntile < tiles_m;
+        if (more) fetch(ntile, nk);  // next stage's global loads fly under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < NT_BK / 16; ++ks) {
+            const int kk = ks * 16 + (lane >> 5) * 8;
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[(wave * 32 + (lane & 31)) * NT_LD + kk]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(j * 32 + (lane & 31)) * NT_LD + kk]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (k0 + NT_BK >= K) {
+            // tile done.  C/D map of a 32x32 tile: col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*(lane >> 5)
+            const long m0 = tile * NT_BM;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + j * 32 + (lane & 31);
+                float sv = 0.0f, sq = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const long r = m0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    const u16 h = f2bf(acc[j][i]);
+                    if (r < R && n < N) out[r * N + n] = h;
+                    if (STATS) {
+                        const float v = bf2f(h);  // statistics of the values the next kernels will read
+                        sv += v;
+                        sq = fmaf(v, v, sq);
+                    }
+                    acc[j][i] = 0.0f;
+                }
+                if (STATS) {
+                    atomicAdd(&ssum[j * 32 + (lane & 31)], sv);
+                    atomicAdd(&ssum[NT_BN + j * 32 + (lane & 31)], sq);
+                }
+            }
+        }
+        if (!more) break;
+        tile = ntile;
+        k0 = nk;
+    }
+    if (STATS) {
+        __syncthreads();
+        if (t < NT_BN && n0 + t < N) {
+            atomicAdd(&sums[n0 + t], ssum[t]);
+            atomicAdd(&sums[N + n0 + t], ssum[NT_BN + t]);
+        }
+    }
+}
+
+// ---- gemm_tn (weight gradient) ----------------------------------------------------------------
+constexpr int TN_BM = 128, TN_BN = 128, TN_RS = 32;  // RS rows of the reduction per stage
+constexpr int TN_LD = 128 + 32;                       // row stride 320 B: conflict-free tr reads
+
+template <int APRO, int BPRO>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(Operand A_arg, Operand B_arg, long R, int M, int N,
+                                                       long rows_per_split, float *__restrict__ part)
+{
+    const Operand A = local_copy(A_arg);
+    const Operand B = local_copy(B_arg);
+    __shared__ __attribute__((aligned(16))) u16 As[TN_RS * TN_LD];
+    __shared__ __attribute__((aligned(16))) u16 Bs[TN_RS * TN_LD];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 outputs each
+    const int m0 = blockIdx.x * TN_BM;
+    const int n0 = blockIdx.y * TN_BN;
+    const long r_begin = (long)blockIdx.z * rows_per_split;
+    const long r_end = r_begin + rows_per_split < R ? r_begin + rows_per_split : R;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    // staging: 32 rows x 16 chunks of 8 columns per operand -> 2 chunks per thread and operand.
+    // A thread's column chunk never changes, so its per-column constants stay in registers.
+    const int chunk = t & 15;
+    const int rrow = t >> 4;  // 0..15
+    Consts<APRO> ka;
+    Consts<BPRO> kb;
+    ka.load(A, m0 + chunk * 8, M);
+    kb.load(B, n0 + chunk * 8, N);
+    Raw<APRO> ra[2];
+    Raw<BPRO> rb[2];
+    auto fetch = [&](long r0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long r = r0 + rrow + 16 * i;
+            ra[i].load(A, r < r_end ? r : R, m0 + chunk * 8, R, M);
+            rb[i].load(B, r < r_end ? r : R, n0 + chunk * 8, R, N);
+        }
+    };
+    // transposed-read addresses: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a
+    // 4 x 16 block; group g covers columns 16*(g&1).. of a 32-wide MFMA tile and k rows 8*(g>>1)..
+    const int grp = lane >> 4, gi = lane & 15;
+    const int tr_row = 8 * (grp >> 1) + (gi >> 2);
+    const int tr_col = 16 * (grp & 1) + 4 * (gi & 3);
+
+    if (r_begin < r_end) fetch(r_begin);
+    for (long r0 = r_begin; r0 < r_end; r0 += TN_RS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4 *>(&As[(rrow + 16 * i) * TN_LD + chunk * 8]) = ra[i].finish(ka, A.act);
+            *reinterpret_cast<uint4 *>(&Bs[(rrow + 16 * i) * TN_LD + chunk * 8]) = rb[i].finish(kb, B.act);
+        }
+        __syncthreads();
+        if (r0 + TN_RS < r_end) fetch(r0 + TN_RS);
+#pragma unroll
+        for (int ks = 0; ks < TN_RS / 16; ++ks) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const u16 *pa = &As[(ks * 16 + tr_row) * TN_LD + wm * 64 + x * 32 + tr_col];
+                const u16 *pb = &Bs[(ks * 16 + tr_row) * TN_LD + wn * 64 + x * 32 + tr_col];
+                typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+                const s16x4 a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pa);
+                const s16x4 a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pa + 4 * TN_LD));
+                const s16x4 b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pb);
+                const s16x4 b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pb + 4 * TN_LD));
+                af[x] = __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[x] = __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 64 + b * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                // one plain store per element into this split's slab (summed by reduce_slabs_kernel):
+                // thousands of workgroups adding into one small dW would serialise on its few lines
+                if (m < M && n < N) part[((long)blockIdx.z * M + m) * N + n] = acc[a][b][i];
+            }
+        }
+}
+
+// dW[e] = sum over splits of part[s][e], in a fixed order (bitwise reproducible weight gradient).
+// 64 consecutive elements x 16 split-lanes per workgroup: coalesced slab reads, LDS tree at the end.
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restrict__ part, int splits,
+                                                             long elems, float *__restrict__ dW)
+{
+    __shared__ float red[16][64];
+    const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    for (long e0 = (long)blockIdx.x * 64; e0 < elems; e0 += (long)gridDim.x * 64) {
+        const long e = e0 + ex;
+        float a = 0.0f;
+        if (e < elems)
+            for (int s = sy; s < splits; s += 16) a += part[(long)s * elems + e];
+        red[sy][ex] = a;
+        __syncthreads();
+        if (sy == 0 && e < elems) {
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][ex];
+            dW[e] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// p, q of the fused BatchNorm backward and the affine-parameter gradients of one layer.
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ sums, long rows, int C,
+                                       const float *__restrict__ scale, const float *__restrict__ mean,
+                                       const float *__restrict__ invstd, int use_batch_stats,
+                                       float *__restrict__ p, float *__restrict__ q)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (!use_batch_stats) {
+        p[c] = 0.0f;
+        q[c] = 0.0f;
+        return;
+    }
+    const float invR = 1.0f / (float)rows;
+    const float a = sums[c] * invR;       // mean of du
+    const float b = sums[C + c] * invR;   // mean of du * xhat
+    const float sb = scale[c] * b * invstd[c];
+    p[c] = -sb;
+    q[c] = fmaf(sb, mean[c], -scale[c] * a);
+}
+
+template <int PRO>
+void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, float *sums, hipStream_t st)
+{
+    long tiles = (R + NT_BM - 1) / NT_BM;
+    const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
+    const long resident = 512 / ny > 0 ? 512 / ny : 1;  // ~2 workgroups per CU in total, persistent over row tiles
+    const dim3 grid((unsigned)(tiles < resident ? tiles : resident), ny);
+    if (sums)
+        hipLaunchKernelGGL((gemm_nt_kernel<PRO, 1>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<PRO, 0>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums);
+}
+
+// Row splits of the weight-gradient GEMM: enough workgroups to fill the chip (~1024), at least 8
+// stages of work each.  Returns the split count; *rows_per_split is a multiple of TN_RS.
+long tn_splits(long R, int M, int N, long *rows_per_split)
+{
+    const long tiles = (long)((M + TN_BM - 1) / TN_BM) * ((N + TN_BN - 1) / TN_BN);
+    long splits = (512 + tiles - 1) / tiles;
+    const long max_splits = (R + 8 * TN_RS - 1) / (8 * TN_RS);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long rps = (R + splits - 1) / splits;
+    rps = (rps + TN_RS - 1) / TN_RS * TN_RS;
+    *rows_per_split = rps;
+    return (R + rps - 1) / rps;
+}
+
+template <int APRO>
+void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int N, float *part, float *dW,
+               hipStream_t st)
+{
+    long rps;
+    const long splits = tn_splits(R, M, N, &rps);
+    const dim3 grid((M + TN_BM - 1) / TN_BM, (N + TN_BN - 1) / TN_BN, (unsigned)splits);
+    if (bpro == PRO_PLAIN)
+        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part);
+    const long elems = (long)M * N;
+    long blocks = (elems + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, part, (int)splits, elems, dW);
+}
+
+inline bool bad_dim(long v) { return v <= 0 || (v & 7) != 0; }
+
+}  // namespace
+
+// A-operand description shared by the C entry points (all pointers may be NULL where unused):
+//   pro 0 plain: a0;  1 BN+act on load: a0, scale, shift, act;
+//   2 dy from dense dz: a0 = dz, a1 = y, scale, shift, p, q, act;
+//   3 dy from a pooled layer: dout, arg, ns, a1 = y, scale, shift, p, q, act.
+static Operand make_operand(const void *a0, const void *a1, long ld, const float *scale, const float *shift,
+                            const float *p, const float *q, const float *dout, const unsigned char *arg,
+                            int ns, int act)
+{
+    Operand o;
+    o.a0 = (const u16 *)a0;
+    o.a1 = (const u16 *)a1;
+    o.ld = ld;
+    o.scale = scale;
+    o.shift = shift;
+    o.p = p;
+    o.q = q;
+    o.dout = dout;
+    o.arg = arg;
+    o.ns = ns > 0 ? ns : 1;
+    o.act = act;
+    return o;
+}
+
+extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale,
+                                const float *shift, const float *p, const float *q, const float *dout,
+                                const unsigned char *argmax, int ns, int act, const void *w, long R, int N,
+                                int K, void *out, float *sums, void *stream)
+{
+    if (!w || !out || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
+    if (pro < 0 || pro > 3) return PCB_ERR_INVALID_ARG;
+    if ((pro <= PRO_DY && !a0) || (pro >= PRO_DY && !a1) || (pro >= PRO_BNACT && (!scale || !shift))) return PCB_ERR_INVALID_ARG;
+    if (pro >= PRO_DY && (!p || !q)) return PCB_ERR_INVALID_ARG;
+    if (pro == PRO_DY_POOL && (!dout || !argmax || ns <= 0 || ns > 255)) return PCB_ERR_INVALID_ARG;
+    const Operand A = make_operand(a0, a1, K, scale, shift, p, q, dout, argmax, ns, act);
+    hipStream_t st = (hipStream_t)stream;
+    switch (pro) {
+        case PRO_PLAIN: launch_nt<PRO_PLAIN>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
+        case PRO_BNACT: launch_nt<PRO_BNACT>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
+        case PRO_DY: launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
+        default: launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
+    }
+    return pcb_check_launch();
+}
+
+extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const float *scale,
+                                const float *shift, const float *p, const float *q, const float *dout,
+                                const unsigned char *argmax, int ns, int act, int bpro, const void *x,
+                                const float *xscale, const float *xshift, int xact, long R, int M, int N,
+                                float *workspace, float *dW, void *stream)
+{
+    if (!x || !dW || !workspace || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(M) || bad_dim(N)) return PCB_ERR_UNSUPPORTED;
+    if (apro != PRO_PLAIN && apro != PRO_DY && apro != PRO_DY_POOL) return PCB_ERR_INVALID_ARG;
+    if (apro != PRO_PLAIN && (!y || !scale || !shift || !p || !q)) return PCB_ERR_INVALID_ARG;
+    if (apro == PRO_DY_POOL ? (!dout || !argmax || ns <= 0 || ns > 255) : !dz) return PCB_ERR_INVALID_ARG;
+    if (bpro != PRO_PLAIN && bpro != PRO_BNACT) return PCB_ERR_INVALID_ARG;
+    if (bpro == PRO_BNACT && (!xscale || !xshift)) return PCB_ERR_INVALID_ARG;
+    const Operand A = make_operand(dz, y, M, scale, shift, p, q, dout, argmax, ns, act);
+    const Operand B = make_operand(x, nullptr, N, xscale, xshift, nullptr, nullptr, nullptr, nullptr, 1, xact);
+    hipStream_t st = (hipStream_t)stream;
+    if (apro == PRO_PLAIN)
+        launch_tn<PRO_PLAIN>(A, B, bpro, R, M, N, workspace, dW, st);
+    else if (apro == PRO_DY)
+        launch_tn<PRO_DY>(A, B, bpro, R, M, N, workspace, dW, st);
+    else
+        launch_tn<PRO_DY_POOL>(A, B, bpro, R, M, N, workspace, dW, st);
+    return pcb_check_launch();
+}
+
+extern "C" long pcb_gemm_tn_workspace(long R, int M, int N)
+{
+    if (R <= 0 || M <= 0 || N <= 0) return 0;
+    long rps;
+    return tn_splits(R, M, N, &rps) * (long)M * N;
+}
+
+extern "C" int pcb_bn_bwd_finalize(const float *sums, long rows, int C, const float *scale,
+                                   const float *mean, const float *invstd, int use_batch_stats, float *p,
+                                   float *q, void *stream)
+{
+    if (!sums || !scale || !mean || !invstd || !p || !q || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
+                       rows, C, scale, mean, invstd, use_batch_stats, p, q);
+    return pcb_check_launch();
+}

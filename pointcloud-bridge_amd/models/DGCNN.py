@@ -13,8 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
-from .pointnet2_utils import _bn_rows, _conv_rows
+from .. import ops, rowmlp
 
 
 class DGCNN(nn.Module):
@@ -56,17 +55,14 @@ class DGCNN(nn.Module):
         return ops.edge_features(xt, idx).permute(0, 3, 1, 2)
 
     # -- forward ------------------------------------------------------------------------------
-    @staticmethod
-    def _lrelu(x):
-        return F.leaky_relu(x, negative_slope=0.2)
-
     def _edge_conv(self, block, x, k):
         """x [B,N,D] channels-last -> [B,N,Cout]: kNN graph, edge features, conv+BN+LeakyReLU, max."""
         B, N, D = x.shape
-        idx = ops.knn(x, k)
-        e = ops.edge_features(x, idx).view(B * N * k, 2 * D)
-        y = self._lrelu(_bn_rows(block[1], _conv_rows(block[0], e)))
-        return y.view(B, N, k, -1).max(dim=2)[0]
+        xf = x.float()
+        idx = ops.knn(xf, k)  # the graph is always built from fp32 distances
+        e = ops.edge_features(xf, idx).view(B * N * k, 2 * D)
+        y = rowmlp.conv_bn_act(block[0], block[1], e, rowmlp.ACT_LEAKY, pool=k)
+        return y.view(B, N, -1)
 
     def forward(self, xyz, features=None):
         """xyz [B,N,3], features [B,N,C] (ignored, as in the reference :123-128) -> logits [B,N,classes]."""
@@ -78,11 +74,11 @@ class DGCNN(nn.Module):
         x3 = self._edge_conv(self.conv3, x2, k)
         x4 = self._edge_conv(self.conv4, x3, k)
         local = torch.cat((x1, x2, x3, x4), dim=2).view(B * N, 320)
-        local_norm = self._lrelu(_bn_rows(self.local_bn, local))
-        g = self._lrelu(_bn_rows(self.conv5[1], _conv_rows(self.conv5[0], local)))
+        local_norm = rowmlp.bn_act_rows(self.local_bn, local, rowmlp.ACT_LEAKY)
+        g = rowmlp.conv_bn_act(self.conv5[0], self.conv5[1], local, rowmlp.ACT_LEAKY)
         g = g.view(B, N, 1024).max(dim=1, keepdim=True)[0]  # adaptive_max_pool1d(x, 1), :160
         pf = torch.cat([local_norm.view(B, N, 320), g.expand(-1, N, -1)], dim=2).view(B * N, 1344)
         pc = self.point_conv
-        pf = self._lrelu(_bn_rows(pc[1], _conv_rows(pc[0], pf)))
-        pf = self._lrelu(_bn_rows(pc[4], _conv_rows(pc[3], pf)))
-        return _conv_rows(pc[6], pf).view(B, N, -1)
+        pf = rowmlp.conv_bn_act(pc[0], pc[1], pf, rowmlp.ACT_LEAKY)
+        pf = rowmlp.conv_bn_act(pc[3], pc[4], pf, rowmlp.ACT_LEAKY)
+        return rowmlp.conv_rows(pc[6], pf, torch.float32).view(B, N, -1)

@@ -10,8 +10,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import rowmlp
 from .pointnet2_utils import (EnhancedFeaturePropagation, FeaturePropagation, MultiScaleSetAbstraction,
-                              SetAbstraction)
+                              SetAbstraction, _channels_last, _seq_rows)
 
 # (npoint, radius, nsample, in_channel, mlp) -- models/model.py:17-19 == models/pointnet2.py:20-22
 _SSG_ENCODER = [
@@ -58,8 +59,10 @@ class PointNet2(nn.Module):
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, points if self.rgb_skip else None, l1)
-        feat = self.drop1(F.relu(self.bn1(self.conv1(l0))))
-        return self.conv2(feat)
+        B, _, N = l0.shape
+        feat = rowmlp.conv_bn_act(self.conv1, self.bn1, _channels_last(l0).view(B * N, -1))
+        logits = rowmlp.conv_rows(self.conv2, self.drop1(feat), torch.float32)
+        return logits.view(B, N, -1).transpose(1, 2)
 
 
 class MultiScaleFeatureFusion(nn.Module):
@@ -72,8 +75,19 @@ class MultiScaleFeatureFusion(nn.Module):
             for c in in_channels_list)
 
     def forward(self, features_list):
+        """[B,C_i,S_i] levels -> [B, N, 3*out] channels-last rows (nearest resampling along the
+        point axis, exactly F.interpolate(feat, size=N) of models/model.py:164)."""
         n = features_list[2].shape[2]
-        return torch.cat([conv(F.interpolate(f, size=n)) for f, conv in zip(features_list, self.convs)], dim=1)
+        outs = []
+        for f, conv in zip(features_list, self.convs):
+            B, _, S = f.shape
+            rows = _channels_last(f)
+            if S != n:
+                ramp = torch.arange(S, dtype=torch.float32, device=f.device).view(1, 1, S)
+                src = F.interpolate(ramp, size=n).view(n).long()  # the very index map F.interpolate uses
+                rows = rows.index_select(1, src)
+            outs.append(_seq_rows(conv, rows.reshape(B * n, -1)).view(B, n, -1))
+        return torch.cat(outs, dim=2)
 
 
 class PointNet2MSG(nn.Module):
@@ -110,4 +124,9 @@ class PointNet2MSG(nn.Module):
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, feats, l1)
-        return self.final_fusion(self.fusion([l2, l1, l0]))
+        fused = self.fusion([l2, l1, l0])  # [B,N,384] channels-last
+        B, N, _ = fused.shape
+        ff = self.final_fusion
+        x = rowmlp.conv_bn_act(ff[0], ff[1], fused.view(B * N, -1))
+        logits = rowmlp.conv_rows(ff[4], ff[3](x), torch.float32)
+        return logits.view(B, N, -1).transpose(1, 2)

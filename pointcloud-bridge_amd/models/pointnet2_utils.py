@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import ops, rowmlp
 
 
 # ---------------------------------------------------------------------------------------------
@@ -61,36 +61,8 @@ def sample_and_group(npoint, radius, nsample, xyz, points):
 
 
 # ---------------------------------------------------------------------------------------------
-# pointwise layers on channels-last rows, driven by the stock sub-modules' parameters
+# pointwise layers on channels-last rows: ..rowmlp (fp32 parity mode or bf16 fused-kernel mode)
 # ---------------------------------------------------------------------------------------------
-def _conv_rows(conv, x):
-    """1x1 Conv1d/Conv2d as a row GEMM: x [rows, Cin] -> [rows, Cout]."""
-    w = conv.weight.view(conv.out_channels, conv.in_channels)
-    return F.linear(x, w, conv.bias)
-
-
-def _bn_rows(bn, x):
-    """BatchNorm1d/2d over rows [rows, C] with the module's exact running-stat bookkeeping."""
-    if isinstance(bn, nn.SyncBatchNorm):
-        return bn(x)  # statistics all-reduced over the process group (parallel.sync_batchnorm)
-    eaf = 0.0 if bn.momentum is None else bn.momentum
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        eaf = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
-    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
-    return F.batch_norm(
-        x,
-        bn.running_mean if (not bn.training or bn.track_running_stats) else None,
-        bn.running_var if (not bn.training or bn.track_running_stats) else None,
-        bn.weight, bn.bias, use_batch, eaf, bn.eps)
-
-
-def _mlp_rows(convs, bns, x):
-    for conv, bn in zip(convs, bns):
-        x = F.relu(_bn_rows(bn, _conv_rows(conv, x)))
-    return x
-
-
 def _channels_last(points):
     """[B,C,N] (any strides) -> contiguous [B,N,C]; free when `points` came out of this module."""
     return points.transpose(1, 2).contiguous()
@@ -98,17 +70,26 @@ def _channels_last(points):
 
 def _seq_rows(seq, x):
     """Run an nn.Sequential of Conv1d / BatchNorm1d / ReLU / Sigmoid on rows."""
-    for m in seq:
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
         if isinstance(m, (nn.Conv1d, nn.Conv2d)):
-            x = _conv_rows(m, x)
-        elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
-            x = _bn_rows(m, x)
+            if i + 1 < len(mods) and isinstance(mods[i + 1], (nn.BatchNorm1d, nn.BatchNorm2d, nn.SyncBatchNorm)):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                x = rowmlp.conv_bn_act(m, mods[i + 1], x, rowmlp.ACT_RELU if relu else rowmlp.ACT_NONE)
+                i += 3 if relu else 2
+                continue
+            x = rowmlp.conv_rows(m, x)
         elif isinstance(m, nn.ReLU):
             x = F.relu(x)
         elif isinstance(m, nn.Sigmoid):
             x = torch.sigmoid(x)
+        elif isinstance(m, nn.Dropout):
+            x = m(x)
         else:
             raise TypeError(f"unsupported layer in pointwise stack: {type(m).__name__}")
+        i += 1
     return x
 
 
@@ -131,11 +112,13 @@ class SetAbstraction(nn.Module):
     def forward(self, xyz, points):
         """xyz [B,N,3], points [B,C,N] or None -> new_xyz [B,S,3], new_points [B,mlp[-1],S]."""
         feat = None if points is None else _channels_last(points)
-        new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, feat)
-        B, S, ns, cin = grouped.shape
-        x = _mlp_rows(self.mlp_convs, self.mlp_bns, grouped.view(B * S * ns, cin))
-        x = x.view(B, S, ns, -1).max(dim=2)[0]
-        return new_xyz, x.transpose(1, 2)
+        B = xyz.shape[0]
+        fps_idx = farthest_point_sample(xyz, self.npoint)
+        new_xyz = index_points(xyz, fps_idx)
+        idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+        rows, perm = rowmlp.group_rows(xyz, new_xyz, feat, idx)
+        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, rows, pool=self.nsample, perm=perm)
+        return new_xyz, x.view(B, self.npoint, -1).transpose(1, 2)
 
 
 class MultiScaleSetAbstraction(nn.Module):
@@ -168,12 +151,12 @@ class MultiScaleSetAbstraction(nn.Module):
         else:
             idx_list = [query_ball_point(r, ns, xyz, new_xyz)
                         for r, ns in zip(self.radius_list, self.nsample_list)]
+        B = xyz.shape[0]
         outs = []
         for i, idx in enumerate(idx_list):
-            grouped = ops.group_points(xyz, new_xyz, feat, idx)
-            B, S, ns, cin = grouped.shape
-            x = _mlp_rows(self.conv_blocks[i], self.bn_blocks[i], grouped.view(B * S * ns, cin))
-            outs.append(x.view(B, S, ns, -1).max(dim=2)[0])
+            rows, perm = rowmlp.group_rows(xyz, new_xyz, feat, idx)
+            x = rowmlp.mlp_rows(self.conv_blocks[i], self.bn_blocks[i], rows, pool=idx.shape[2], perm=perm)
+            outs.append(x.view(B, self.npoint, -1))
         return new_xyz, torch.cat(outs, dim=2).transpose(1, 2)
 
 
@@ -187,7 +170,9 @@ def _interpolate(xyz1, xyz2, points2, k):
         raise RuntimeError("feature propagation from a single centroid (S == 1) fails in the reference "
                            "(shape mismatch in its repeat branch) and is not supported")
     d2, idx = ops.three_nn(xyz1, xyz2, k)
-    return ops.three_interpolate(_channels_last(points2), d2, idx)
+    feat = _channels_last(points2)
+    out = ops.three_interpolate(feat.float(), d2, idx)
+    return out.to(feat.dtype)
 
 
 class FeaturePropagation(nn.Module):
@@ -207,8 +192,8 @@ class FeaturePropagation(nn.Module):
         B, N, _ = xyz1.shape
         x = _interpolate(xyz1, xyz2, points2, 3)
         if points1 is not None:
-            x = torch.cat([_channels_last(points1), x], dim=-1)  # skip features FIRST (:201)
-        x = _mlp_rows(self.mlp_convs, self.mlp_bns, x.reshape(B * N, -1))
+            x = torch.cat([_channels_last(points1).to(x.dtype), x], dim=-1)  # skip features FIRST (:201)
+        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x.reshape(B * N, -1))
         return x.view(B, N, -1).transpose(1, 2)
 
 
@@ -240,12 +225,12 @@ class EnhancedFeaturePropagation(nn.Module):
         B, N, _ = xyz1.shape
         x = _interpolate(xyz1, xyz2, points2, 4)
         if points1 is not None:
-            x = torch.cat([_channels_last(points1), x], dim=-1)
+            x = torch.cat([_channels_last(points1).to(x.dtype), x], dim=-1)
         x = x.reshape(B * N, -1)
         x = x * _seq_rows(self.attention, x)                       # :279-280
         edge = _seq_rows(self.boundary_aware, xyz1.reshape(B * N, 3))  # :283
         identity = x
-        x = _mlp_rows(self.mlp_convs, self.mlp_bns, x)
+        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x)
         if self.skip_connection:
             x = x + identity                                        # :292-293
         x = x + edge                                                # :296

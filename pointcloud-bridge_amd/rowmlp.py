@@ -1,0 +1,519 @@
+"""Shared pointwise MLP on channels-last rows: Conv(1x1) -> BatchNorm -> activation [-> max over
+the neighbour axis], the block the reference repeats in every SetAbstraction / FeaturePropagation /
+EdgeConv layer (models/pointnet2_utils.py:149-154, :207-209, :353-356; models/DGCNN.py:134-148).
+
+Two numerically distinct execution modes, selected with `set_precision`:
+
+  "fp32"  (default)  torch row GEMM + ATen BatchNorm on fp32 rows.  This is the parity mode: network
+                     logits stay within 1e-4 relative of the reference (tests/test_gpu_modules.py).
+  "bf16"             bf16 activations / fp32 statistics and master weights.  Per layer only the
+                     pre-BatchNorm GEMM output is kept; statistics, normalisation, activation,
+                     pooling and the BatchNorm backward are hand-written gfx950 kernels
+                     (csrc/rowbn.hip through the C ABI).  This is the throughput mode bench.py runs
+                     (BASELINE.json config 2 names bf16).
+
+Both modes read the parameters of the caller's stock nn.Conv*/nn.BatchNorm* modules and keep their
+running statistics exactly as nn.BatchNorm does, so state_dicts stay interchangeable.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import _launch
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+_PRECISION = "fp32"
+# bf16 engine: "fused" = own MFMA GEMMs with fused BatchNorm algebra (csrc/gemm.hip);
+# "staged" = hipBLASLt GEMMs (torch.mm) + the row kernels of csrc/rowbn.hip (kept for A/B timing)
+_ENGINE = "fused"
+
+
+def set_engine(name):
+    global _ENGINE
+    if name not in ("fused", "staged"):
+        raise ValueError(name)
+    _ENGINE = name
+
+
+def set_precision(mode):
+    """'fp32' (parity mode) or 'bf16' (fused bf16 row kernels)."""
+    global _PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {mode!r}")
+    _PRECISION = mode
+
+
+def get_precision():
+    return _PRECISION
+
+
+def is_bf16():
+    return _PRECISION == "bf16"
+
+
+def pad8(k):
+    return (k + 7) // 8 * 8
+
+
+def _act_torch(x, act):
+    if act == ACT_RELU:
+        return F.relu(x)
+    if act == ACT_LEAKY:
+        return F.leaky_relu(x, negative_slope=0.2)
+    return x
+
+
+def _weight2d(conv):
+    return conv.weight.view(conv.out_channels, conv.in_channels)
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32 parity mode
+# ---------------------------------------------------------------------------------------------
+def _bn_rows_fp32(bn, x):
+    """BatchNorm1d/2d over rows [rows, C] with the module's exact running-stat bookkeeping."""
+    if isinstance(bn, nn.SyncBatchNorm):
+        return bn(x)  # statistics all-reduced over the process group (parallel.sync_batchnorm)
+    eaf = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        eaf = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    return F.batch_norm(
+        x,
+        bn.running_mean if (not bn.training or bn.track_running_stats) else None,
+        bn.running_var if (not bn.training or bn.track_running_stats) else None,
+        bn.weight, bn.bias, use_batch, eaf, bn.eps)
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16 mode
+# ---------------------------------------------------------------------------------------------
+def _mm_f32out(a, b):
+    """a @ b with bf16 operands and an fp32 result (weight gradients keep fp32 precision)."""
+    try:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):
+        return torch.mm(a, b).float()
+
+
+def padded_weight(conv, kp, perm_feat_first=0):
+    """[Cout, kp] bf16 copy of a 1x1 conv weight, zero padded.  perm_feat_first = C > 0 moves the
+    first 3 input columns (centred coordinates, reference order :56/:347) behind the C feature
+    columns, the order pcb_group_rows_bf16 writes."""
+    w = _weight2d(conv)
+    cout, k = w.shape
+    wp = torch.zeros(cout, kp, dtype=torch.bfloat16, device=w.device)
+    if perm_feat_first > 0:
+        c = perm_feat_first
+        wp[:, :c] = w[:, 3:3 + c]
+        wp[:, c:c + 3] = w[:, :3]
+    else:
+        wp[:, :k] = w
+    return wp
+
+
+class _LinearBNAct(torch.autograd.Function):
+    """x [R,Kp] bf16 -> act(BN(x @ W^T)) as rows [R,C] bf16, or pooled over `pool` consecutive rows
+    ([R/pool, C] bf16).  Saves x, the bf16 GEMM output y and the per-channel statistics only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
+                act, pool, perm):
+        R, Kp = x.shape
+        C = weight.shape[0]
+        dev = x.device
+        wp = padded_weight_from(weight, Kp, perm)
+        y = torch.mm(x, wp.t())
+        stats = torch.zeros(6, C, dtype=torch.float32, device=dev)  # sums(2) | scale | shift | mean | invstd
+        sums, scale, shift, mean, invstd = stats[0:2], stats[2], stats[3], stats[4], stats[5]
+        with torch.cuda.device(dev):
+            if training:
+                _launch("pcb_colstats_bf16", R * C, y.data_ptr(), R, C, sums.data_ptr())
+            _launch("pcb_bn_finalize", C, sums.data_ptr(), R, C,
+                    0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
+                    0 if bias is None else bias.data_ptr(),
+                    0 if running_mean is None else running_mean.data_ptr(),
+                    0 if running_var is None else running_var.data_ptr(),
+                    float(momentum), float(eps), int(training), scale.data_ptr(), shift.data_ptr(),
+                    mean.data_ptr(), invstd.data_ptr())
+            if pool:
+                G = R // pool
+                out = torch.empty(G, C, dtype=torch.bfloat16, device=dev)
+                arg = torch.empty(G, C, dtype=torch.uint8, device=dev)
+                _launch("pcb_bn_act_max_bf16", R * C, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), G,
+                        pool, C, act, out.data_ptr(), arg.data_ptr())
+            else:
+                arg = None
+                out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+                _launch("pcb_bn_act_bf16", R * C, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), R, C, act,
+                        out.data_ptr())
+        ctx.save_for_backward(x, wp, y, stats, arg)
+        ctx.cfg = (int(training), act, pool, perm, weight.shape, bias is not None, gamma is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wp, y, stats, arg = ctx.saved_tensors
+        training, act, pool, perm, wshape, has_bias, has_affine = ctx.cfg
+        R, Kp = x.shape
+        C = wp.shape[0]
+        dev = x.device
+        scale, shift, mean, invstd = stats[2], stats[3], stats[4], stats[5]
+        bsums = torch.zeros(2, C, dtype=torch.float32, device=dev)
+        dy = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            if pool:
+                g32 = g.float().contiguous()
+                _launch("pcb_bn_act_max_bwd_bf16", R * C, g32.data_ptr(), arg.data_ptr(), y.data_ptr(),
+                        scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R // pool,
+                        pool, C, act, training, bsums.data_ptr(), dy.data_ptr())
+            else:
+                gb = g.to(torch.bfloat16).contiguous()
+                _launch("pcb_bn_act_bwd_bf16", R * C, gb.data_ptr(), y.data_ptr(), scale.data_ptr(),
+                        shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R, C, act, training,
+                        bsums.data_ptr(), dy.data_ptr())
+        dx = torch.mm(dy, wp) if ctx.needs_input_grad[0] else None
+        dwp = _mm_f32out(dy.t(), x)  # [C, Kp]
+        cout, k = wshape[0], wshape[1]
+        if perm > 0:
+            dw = torch.cat([dwp[:, perm:perm + 3], dwp[:, :perm]], dim=1)
+        else:
+            dw = dwp[:, :k]
+        dw = dw.reshape(wshape)
+        # d(bias): sum of dy over rows -- exactly zero under batch statistics, scale*s1 otherwise
+        dbias = None
+        if has_bias:
+            dbias = torch.zeros(C, dtype=torch.float32, device=dev) if training else scale * bsums[0]
+        dgamma = bsums[1].clone() if has_affine else None
+        dbeta = bsums[0].clone() if has_affine else None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def padded_weight_from(weight, kp, perm):
+    """Same as padded_weight but from the raw weight tensor ([Cout, K] or [Cout, K, 1(,1)])."""
+    w = weight.reshape(weight.shape[0], -1)
+    cout, k = w.shape
+    wp = torch.zeros(cout, kp, dtype=torch.bfloat16, device=w.device)
+    if perm > 0:
+        wp[:, :perm] = w[:, 3:3 + perm]
+        wp[:, perm:perm + 3] = w[:, :3]
+    else:
+        wp[:, :k] = w
+    return wp
+
+
+def _bn_bookkeeping(bn):
+    """momentum to use for this call + the num_batches_tracked increment of nn.BatchNorm.forward."""
+    eaf = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        eaf = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+    return eaf
+
+
+def _rows_bf16(x, kp):
+    """Make x [R,K] a contiguous bf16 [R,kp] operand (zero padded on the right)."""
+    x = x.to(torch.bfloat16)
+    if x.shape[1] == kp:
+        return x.contiguous()
+    return F.pad(x, (0, kp - x.shape[1]))
+
+
+class _FusedStack(torch.autograd.Function):
+    """A stack of L layers act(BN(. W^T)) on bf16 rows with everything between the GEMMs fused
+    (csrc/gemm.hip): layer l's BatchNorm+activation is applied while layer l+1 loads its operand,
+    batch statistics come out of the GEMM epilogue, the backward recomputes dy on load.  Per layer
+    only y_l = x_l W_l^T is stored.  The last layer's activation is materialised (rows) or
+    max-pooled over `pool` consecutive rows.
+
+    Flat argument list: x, act, pool, perm, L, then per layer
+    (weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps)."""
+
+    NPER = 9
+
+    @staticmethod
+    def forward(ctx, x, act, pool, perm, L, *flat):
+        dev = x.device
+        R = x.shape[0]
+        layers = [flat[i * _FusedStack.NPER:(i + 1) * _FusedStack.NPER] for i in range(L)]
+        ys, wps, stats = [], [], []
+        cur, cur_k = x, x.shape[1]
+        with torch.cuda.device(dev):
+            for l, (w, bias, gamma, beta, rm, rv, training, momentum, eps) in enumerate(layers):
+                C = w.shape[0]
+                wp = padded_weight_from(w, cur_k, perm if l == 0 else 0)
+                y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+                st = torch.zeros(10, C, dtype=torch.float32, device=dev)  # sums2|scale|shift|mean|invstd|bsums2|p|q
+                prev = stats[-1] if l else None
+                _launch("pcb_gemm_nt_bf16", R * C * cur_k, 1 if l else 0, cur.data_ptr(), 0,
+                        prev[2].data_ptr() if l else 0, prev[3].data_ptr() if l else 0, 0, 0, 0, 0, 0, act,
+                        wp.data_ptr(), R, C, cur_k, y.data_ptr(), st[0:2].data_ptr() if training else 0)
+                _launch("pcb_bn_finalize", C, st[0:2].data_ptr(), R, C,
+                        0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
+                        0 if bias is None else bias.data_ptr(), 0 if rm is None else rm.data_ptr(),
+                        0 if rv is None else rv.data_ptr(), float(momentum), float(eps), int(training),
+                        st[2].data_ptr(), st[3].data_ptr(), st[4].data_ptr(), st[5].data_ptr())
+                ys.append(y)
+                wps.append(wp)
+                stats.append(st)
+                cur, cur_k = y, C
+            st = stats[-1]
+            C = cur_k
+            if pool:
+                G = R // pool
+                out = torch.empty(G, C, dtype=torch.bfloat16, device=dev)
+                arg = torch.empty(G, C, dtype=torch.uint8, device=dev)
+                _launch("pcb_bn_act_max_bf16", R * C, cur.data_ptr(), st[2].data_ptr(), st[3].data_ptr(), G, pool,
+                        C, act, out.data_ptr(), arg.data_ptr())
+            else:
+                arg = None
+                out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+                _launch("pcb_bn_act_bf16", R * C, cur.data_ptr(), st[2].data_ptr(), st[3].data_ptr(), R, C, act,
+                        out.data_ptr())
+        ctx.save_for_backward(x, arg, *ys, *wps, *stats)
+        ctx.cfg = (act, pool, perm, L, [int(t[6]) for t in layers], [t[0].shape for t in layers],
+                   [t[1] is not None for t in layers], [t[2] is not None for t in layers])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        act, pool, perm, L, trainings, wshapes, has_bias, has_affine = ctx.cfg
+        saved = ctx.saved_tensors
+        x, arg = saved[0], saved[1]
+        ys, wps, stats = saved[2:2 + L], saved[2 + L:2 + 2 * L], saved[2 + 2 * L:2 + 3 * L]
+        dev = x.device
+        R = x.shape[0]
+        grads = [None] * (L * _FusedStack.NPER)
+        dz = None  # dense upstream gradient of layer l's activation (bf16 rows)
+        with torch.cuda.device(dev):
+            if pool:
+                dout = g.float().contiguous()
+            else:
+                dz = g.to(torch.bfloat16).contiguous()
+            for l in range(L - 1, -1, -1):
+                y, wp, st = ys[l], wps[l], stats[l]
+                C, K = wp.shape
+                training = trainings[l]
+                pooled = pool and l == L - 1
+                scale, shift, mean, invstd, bsums, p, q = st[2], st[3], st[4], st[5], st[6:8], st[8], st[9]
+                if pooled:
+                    _launch("pcb_bn_act_max_bwd_reduce_bf16", R * C, dout.data_ptr(), arg.data_ptr(), y.data_ptr(),
+                            scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R // pool, pool,
+                            C, act, bsums.data_ptr())
+                else:
+                    _launch("pcb_bn_act_bwd_reduce_bf16", R * C, dz.data_ptr(), y.data_ptr(), scale.data_ptr(),
+                            shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R, C, act, bsums.data_ptr())
+                _launch("pcb_bn_bwd_finalize", C, bsums.data_ptr(), R, C, scale.data_ptr(), mean.data_ptr(),
+                        invstd.data_ptr(), training, p.data_ptr(), q.data_ptr())
+                apro = 3 if pooled else 2
+                a0 = 0 if pooled else dz.data_ptr()
+                dptr = dout.data_ptr() if pooled else 0
+                aptr = arg.data_ptr() if pooled else 0
+                # weight gradient: dW = dy^T . x_l, with x_l = act(BN(y_{l-1})) recomputed on load
+                dwp = torch.empty(C, K, dtype=torch.float32, device=dev)
+                ws = torch.empty(_lib.load().pcb_gemm_tn_workspace(R, C, K), dtype=torch.float32, device=dev)
+                if l:
+                    ps = stats[l - 1]
+                    _launch("pcb_gemm_tn_bf16", R * C * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                            p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, 1,
+                            ys[l - 1].data_ptr(), ps[2].data_ptr(), ps[3].data_ptr(), act, R, C, K, ws.data_ptr(),
+                            dwp.data_ptr())
+                else:
+                    _launch("pcb_gemm_tn_bf16", R * C * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                            p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, 0, x.data_ptr(), 0, 0,
+                            0, R, C, K, ws.data_ptr(), dwp.data_ptr())
+                # input gradient: dz_{l-1} = dy . W   (skipped for the first layer if x needs none)
+                if l or ctx.needs_input_grad[0]:
+                    wt = wp.t().contiguous()  # [K, C]: row n = input column, contiguous over C
+                    dprev = torch.empty(R, K, dtype=torch.bfloat16, device=dev)
+                    _launch("pcb_gemm_nt_bf16", R * C * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                            p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, wt.data_ptr(), R, K, C,
+                            dprev.data_ptr(), 0)
+                else:
+                    dprev = None
+                # parameter gradients of this layer
+                k = wshapes[l][1]
+                if l == 0 and perm > 0:
+                    dw = torch.cat([dwp[:, perm:perm + 3], dwp[:, :perm]], dim=1)
+                else:
+                    dw = dwp[:, :k]
+                base = l * _FusedStack.NPER
+                grads[base + 0] = dw.reshape(wshapes[l])
+                if has_bias[l]:
+                    grads[base + 1] = (torch.zeros(C, dtype=torch.float32, device=dev) if training
+                                       else scale * bsums[0])
+                if has_affine[l]:
+                    grads[base + 2] = bsums[1].clone()
+                    grads[base + 3] = bsums[0].clone()
+                dz = dprev
+        return (dz, None, None, None, None, *grads)
+
+
+def _stack_fusable(convs, bns):
+    return all(c.out_channels % 8 == 0 and not isinstance(b, nn.SyncBatchNorm) for c, b in zip(convs, bns))
+
+
+def _fused_stack(convs, bns, x, act, pool, perm):
+    kp = x.shape[1] if perm > 0 else pad8(convs[0].in_channels)
+    xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
+    flat = []
+    for conv, bn in zip(convs, bns):
+        momentum = _bn_bookkeeping(bn)
+        training = bn.training or (bn.running_mean is None and bn.running_var is None)
+        track = bn.track_running_stats and bn.running_mean is not None
+        flat += [conv.weight, conv.bias, bn.weight, bn.bias,
+                 bn.running_mean if (track or not training) else None,
+                 bn.running_var if (track or not training) else None,
+                 training, momentum, bn.eps]
+    return _FusedStack.apply(xr, act, pool, perm, len(convs), *flat)
+
+
+# ---------------------------------------------------------------------------------------------
+# public helpers used by the modules
+# ---------------------------------------------------------------------------------------------
+def conv_bn_act(conv, bn, x, act=ACT_RELU, pool=0, perm=0):
+    """act(bn(conv(x))) on rows x [R, K]; with pool = ns also the max over each ns consecutive rows.
+
+    perm = C > 0: x was written by pcb_group_rows_bf16 (C feature columns first, then the 3 centred
+    coordinates); bf16 mode only.  Returns [R, Cout] or [R/pool, Cout] in the mode's dtype."""
+    if not is_bf16():
+        y = _act_torch(_bn_rows_fp32(bn, F.linear(x, _weight2d(conv), conv.bias)), act)
+        if pool:
+            y = y.view(-1, pool, y.shape[1]).max(dim=1)[0]
+        return y
+    if isinstance(bn, nn.SyncBatchNorm):
+        raise NotImplementedError("SyncBatchNorm is supported in fp32 mode only")
+    if conv.out_channels % 8 != 0:
+        # narrow odd widths (not used by the reference's networks): unfused torch ops in bf16
+        y = F.linear(x.to(torch.bfloat16), _weight2d(conv).to(torch.bfloat16),
+                     None if conv.bias is None else conv.bias.to(torch.bfloat16))
+        y = _act_torch(_bn_rows_fp32(bn, y.float()), act).to(torch.bfloat16)
+        if pool:
+            y = y.view(-1, pool, y.shape[1]).max(dim=1)[0]
+        return y
+    if _ENGINE == "fused":
+        return _fused_stack([conv], [bn], x, act, pool, perm)
+    kp = x.shape[1] if perm > 0 else pad8(conv.in_channels)
+    xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
+    momentum = _bn_bookkeeping(bn)
+    training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    track = bn.track_running_stats and bn.running_mean is not None
+    return _LinearBNAct.apply(
+        xr, conv.weight, conv.bias, bn.weight, bn.bias,
+        bn.running_mean if (track or not training) else None,
+        bn.running_var if (track or not training) else None,
+        training, momentum, bn.eps, act, pool, perm)
+
+
+class _LinearBias(torch.autograd.Function):
+    """y = x W^T + b on bf16 rows (no BatchNorm).  Backward: weight gradient with the split-row
+    MFMA kernel (fp32, no atomics), bias gradient as a column sum (pcb_colstats_bf16) instead of
+    ATen's strided bf16 reduction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w = weight.reshape(weight.shape[0], -1)
+        n, k = w.shape
+        npad, kp = pad8(n), x.shape[1]
+        wp = torch.zeros(npad, kp, dtype=torch.bfloat16, device=x.device)
+        wp[:n, :k] = w
+        y = torch.mm(x, wp.t())
+        if bias is not None:
+            y[:, :n] += bias.to(torch.bfloat16)
+        ctx.save_for_backward(x, wp)
+        ctx.cfg = (weight.shape, n, k, bias is not None)
+        return y[:, :n]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wp = ctx.saved_tensors
+        wshape, n, k, has_bias = ctx.cfg
+        npad, kp = wp.shape
+        R = x.shape[0]
+        dev = x.device
+        gy = g.to(torch.bfloat16)
+        gy = gy.contiguous() if npad == n else F.pad(gy, (0, npad - n))
+        dx = torch.mm(gy, wp) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(npad, kp, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        ws = torch.empty(lib.pcb_gemm_tn_workspace(R, npad, kp), dtype=torch.float32, device=dev)
+        sums = torch.zeros(2, npad, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _launch("pcb_gemm_tn_bf16", R * npad * kp, 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
+                    0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr())
+            if has_bias:
+                _launch("pcb_colstats_bf16", R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
+        return dx, dw[:n, :k].reshape(wshape), (sums[0, :n].clone() if has_bias else None)
+
+
+def conv_rows(conv, x, out_dtype=None):
+    """Plain 1x1 conv (with bias) on rows, no BatchNorm.  bf16 mode computes in bf16."""
+    if not is_bf16():
+        return F.linear(x, _weight2d(conv), conv.bias)
+    xr = _rows_bf16(x, pad8(x.shape[1]))
+    y = _LinearBias.apply(xr, conv.weight, conv.bias)
+    return y if out_dtype is None else y.to(out_dtype)
+
+
+def bn_act_rows(bn, x, act=ACT_NONE):
+    """BatchNorm (+ activation) on rows without a preceding conv (DGCNN.local_bn)."""
+    if not is_bf16():
+        return _act_torch(_bn_rows_fp32(bn, x), act)
+    return _act_torch(_bn_rows_fp32(bn, x.float()), act).to(torch.bfloat16)
+
+
+def mlp_rows(convs, bns, x, act=ACT_RELU, pool=0, perm=0):
+    """A stack of conv_bn_act layers; the last one pools if pool > 0."""
+    n = len(convs)
+    if is_bf16() and _ENGINE == "fused" and _stack_fusable(convs, bns):
+        return _fused_stack(list(convs), list(bns), x, act, pool, perm)
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        x = conv_bn_act(conv, bn, x, act, pool if i == n - 1 else 0, perm if i == 0 else 0)
+    return x
+
+
+def group_rows(xyz, new_xyz, feat, idx):
+    """Grouped GEMM input rows for a set-abstraction level.
+
+    fp32 mode: ops.group_points -> [B*S*ns, 3+C] fp32, coordinates first (reference order), perm 0.
+    bf16 mode: pcb_group_rows_bf16 -> [B*S*ns, Kp] bf16, features first, perm = C (see conv_bn_act).
+    Returns (rows, perm)."""
+    from . import ops
+    B, S, ns = idx.shape
+    if not is_bf16():
+        g = ops.group_points(xyz, new_xyz, feat, idx)
+        return g.view(B * S * ns, g.shape[-1]), 0
+    return _GroupRowsBF16.apply(xyz, new_xyz, feat, idx), (0 if feat is None else feat.shape[2])
+
+
+class _GroupRowsBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feat, idx):
+        B, N, _ = xyz.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        C = 0 if feat is None else feat.shape[2]
+        kp = pad8(C + 3)
+        if feat is not None:
+            feat = feat.to(torch.bfloat16).contiguous()
+        out = torch.empty(B * S * ns, kp, dtype=torch.bfloat16, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _launch("pcb_group_rows_bf16", B * S * ns * kp, xyz.data_ptr(), new_xyz.data_ptr(),
+                    0 if feat is None else feat.data_ptr(), idx.data_ptr(), B, N, S, ns, C, kp, out.data_ptr())
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, S, ns, C, kp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, S, ns, C, kp = ctx.shape
+        if C == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None
+        g = g.contiguous()
+        gf = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _launch("pcb_group_rows_bf16_bwd", B * S * ns * C, g.data_ptr(), idx.data_ptr(), B, N, S, ns, C, kp,
+                    gf.data_ptr())
+        return None, None, gf, None

@@ -1,0 +1,254 @@
+"""GPU: the bf16 row kernels (csrc/rowbn.hip) and the bf16 execution mode of the networks.
+
+Each kernel is compared with a plain PyTorch fp32 evaluation of the same operator on the same
+(bf16-rounded) inputs.  Tolerances are bf16's: outputs are rounded to 8 significant bits once,
+statistics and parameter gradients are fp32.  The 1e-4 logit bar belongs to the fp32 mode
+(tests/test_gpu_modules.py); here the bf16 networks are checked against the fp32 networks and on a
+short training run (mIoU parity on a learnable synthetic task).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rm():
+    assert torch.cuda.is_available()
+    from pointcloud_bridge_amd import rowmlp
+    yield rowmlp
+    rowmlp.set_precision("fp32")
+
+
+def _act(u, act):
+    return F.relu(u) if act == 1 else (F.leaky_relu(u, 0.2) if act == 2 else u)
+
+
+def _ste_bf16(y):
+    """Round to bf16 in the forward, identity in the backward (the kernels store y as bf16)."""
+    return y + (y.to(torch.bfloat16).float() - y).detach()
+
+
+def _first_max_pool(h, pool):
+    """max over each `pool` consecutive rows with the gradient routed to the FIRST maximal row (what
+    the kernels do; torch.max leaves the choice among equal values open, and equal bf16 values are
+    common)."""
+    h3 = h.view(-1, pool, h.shape[1])
+    eq = h3 == h3.max(dim=1, keepdim=True)[0]
+    first = eq & (eq.cumsum(dim=1) == 1)
+    return (h3 * first).sum(dim=1)
+
+
+def _close(a, b, tol):
+    # bf16 operands: mean relative error at `tol`, no element further than 4*tol of the largest
+    d = (a.float() - b).abs()
+    return (float(d.mean()) <= tol * max(float(b.abs().mean()), 1e-6)
+            and float(d.max()) <= 4 * tol * max(float(b.abs().max()), 1e-6))
+
+
+@pytest.mark.parametrize("engine", ["fused", "staged"])
+@pytest.mark.parametrize("R,K,C,act,pool", [(4096, 8, 64, 1, 0), (2048, 264, 128, 1, 16), (1536, 128, 64, 2, 8),
+                                            (999 * 4, 72, 256, 0, 0), (640, 520, 512, 1, 32), (77 * 3, 16, 24, 1, 3)])
+def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, engine, R, K, C, act, pool):
+    torch.manual_seed(R + C)
+    dev = "cuda"
+    x = torch.randn(R, K, device=dev).to(torch.bfloat16).requires_grad_(True)
+    conv = nn.Conv1d(K, C, 1).to(dev)
+    bn = nn.BatchNorm1d(C).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    bn_ref = nn.BatchNorm1d(C).to(dev).train()
+    bn_ref.load_state_dict(bn.state_dict())
+
+    rm.set_precision("bf16")
+    rm.set_engine(engine)
+    out = rm.conv_bn_act(conv, bn, x, act, pool)
+    rm.set_engine("fused")
+    rm.set_precision("fp32")
+    assert out.dtype == torch.bfloat16 and out.shape == (R // pool if pool else R, C)
+
+    # reference: fp32 math on the same bf16-rounded operands; y rounded to bf16 as the kernels store it
+    # (the conv bias cancels inside a train-mode BatchNorm, so it is added after the rounding)
+    xr = x.detach().float().requires_grad_(True)
+    w = conv.weight.detach().view(C, K).to(torch.bfloat16).float().requires_grad_(True)
+    y = _ste_bf16(xr @ w.t()) + conv.bias.detach()
+    ref = _act(bn_ref(y), act)
+    if pool:
+        ref = _first_max_pool(ref, pool)
+    scale = float(ref.detach().abs().max())
+    assert float((out.float() - ref).abs().max()) < 2e-2 * scale
+    torch.testing.assert_close(bn.running_mean, bn_ref.running_mean, rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(bn.running_var, bn_ref.running_var, rtol=2e-2, atol=2e-3)
+    assert int(bn.num_batches_tracked) == 1
+
+    g = torch.randn_like(ref)
+    (out.float() * g).sum().backward()
+    (ref * g).sum().backward()
+    assert _close(x.grad, xr.grad, 2e-2)
+    assert _close(conv.weight.grad.view(C, K), w.grad, 2e-2)
+    assert _close(bn.weight.grad, bn_ref.weight.grad, 2e-2)
+    assert _close(bn.bias.grad, bn_ref.bias.grad, 2e-2)
+    assert float(conv.bias.grad.abs().max()) == 0.0  # exactly zero under batch statistics
+
+
+@pytest.mark.parametrize("R,K,widths,act,pool,perm", [(2048, 8, [64, 64, 128], 1, 16, 0), (1024, 264, [128, 128, 256], 1, 32, 0),
+                                                      (3000, 72, [256, 128], 1, 0, 0), (1280, 128, [64], 2, 20, 0),
+                                                      (1536, 24, [32, 32, 64], 1, 8, 16)])
+def test_fused_stack_forward_backward_vs_torch_fp32(rm, R, K, widths, act, pool, perm):
+    """Multi-layer stack: BatchNorm+activation applied on operand load, statistics from the GEMM
+    epilogue, dy recomputed on load in both backward GEMMs -- against a plain fp32 torch stack."""
+    torch.manual_seed(R + K)
+    dev = "cuda"
+    x = torch.randn(R, K, device=dev).to(torch.bfloat16).requires_grad_(True)
+    kin = K if not perm else perm + 3     # real input width when the rows carry padding
+    dims = [kin] + widths
+    convs = nn.ModuleList(nn.Conv2d(a, b, 1) for a, b in zip(dims[:-1], dims[1:])).to(dev)
+    bns = nn.ModuleList(nn.BatchNorm2d(b) for b in widths).to(dev).train()
+    refs = nn.ModuleList(nn.BatchNorm1d(b) for b in widths).to(dev).train()
+    with torch.no_grad():
+        for bn, rf in zip(bns, refs):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+            rf.load_state_dict(bn.state_dict())
+        if perm:
+            x.data[:, kin:] = 0          # padding columns as pcb_group_rows_bf16 writes them
+    rm.set_precision("bf16")
+    out = rm.mlp_rows(convs, bns, x, act, pool, perm)
+    rm.set_precision("fp32")
+
+    xr = x.detach().float().requires_grad_(True)
+    h = xr[:, :kin]
+    if perm:  # rows are [features | xyz]; the reference weight expects [xyz | features]
+        h = torch.cat([h[:, perm:perm + 3], h[:, :perm]], dim=1)
+    ws = []
+    for li, (conv, rf) in enumerate(zip(convs, refs)):
+        w = conv.weight.detach().view(conv.out_channels, -1).to(torch.bfloat16).float().requires_grad_(True)
+        ws.append(w)
+        h = _act(rf(_ste_bf16(h @ w.t()) + conv.bias.detach()), act)
+        if li < len(convs) - 1:
+            h = _ste_bf16(h)  # the next GEMM consumes the activation as bf16
+    ref = _first_max_pool(h, pool) if pool else h
+    assert out.shape == ref.shape
+    assert float((out.float() - ref).abs().max()) < 2e-2 * float(ref.detach().abs().max())
+    g = torch.randn_like(ref)
+    (out.float() * g).sum().backward()
+    (ref * g).sum().backward()
+    assert _close(x.grad[:, :kin], xr.grad[:, :kin], 2e-2)
+    for conv, w, bn, rf in zip(convs, ws, bns, refs):
+        assert _close(conv.weight.grad.view_as(w), w.grad, 2e-2)
+        assert _close(bn.weight.grad, rf.weight.grad, 2e-2)
+        assert _close(bn.bias.grad, rf.bias.grad, 2e-2)
+        torch.testing.assert_close(bn.running_var, rf.running_var, rtol=3e-2, atol=3e-3)
+
+
+def test_eval_mode_uses_running_stats_and_bias(rm):
+    torch.manual_seed(0)
+    dev = "cuda"
+    R, K, C = 1024, 32, 64
+    x = torch.randn(R, K, device=dev)
+    conv = nn.Conv1d(K, C, 1).to(dev)
+    bn = nn.BatchNorm1d(C).to(dev)
+    with torch.no_grad():
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+    bn.eval()
+    rm.set_precision("bf16")
+    out = rm.conv_bn_act(conv, bn, x, 1)
+    rm.set_precision("fp32")
+    ref = F.relu(bn(F.linear(x.to(torch.bfloat16).float(), conv.weight.view(C, K).to(torch.bfloat16).float(), conv.bias)))
+    assert float((out.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+def test_group_rows_bf16_layout_and_backward(rm):
+    from pointcloud_bridge_amd import ops
+    torch.manual_seed(1)
+    B, N, S, ns, C = 2, 300, 40, 8, 16
+    xyz = torch.rand(B, N, 3, device="cuda")
+    new_xyz = xyz[:, :S].contiguous()
+    feat = torch.randn(B, N, C, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    idx = torch.randint(0, N, (B, S, ns), device="cuda")
+    rm.set_precision("bf16")
+    rows, perm = rm.group_rows(xyz, new_xyz, feat, idx)
+    rm.set_precision("fp32")
+    assert perm == C and rows.shape == (B * S * ns, 24) and rows.dtype == torch.bfloat16
+    ref = ops.group_points(xyz, new_xyz, feat.detach().float(), idx).view(-1, 3 + C)
+    assert torch.equal(rows[:, :C].float(), ref[:, 3:])                       # features first, exact copy
+    assert torch.equal(rows[:, C:C + 3], ref[:, :3].to(torch.bfloat16))       # then centred coordinates
+    assert float(rows[:, C + 3:].abs().max()) == 0.0                          # zero padding
+    g = torch.randn(rows.shape, device="cuda").to(torch.bfloat16)
+    rows.backward(g)
+    want = torch.zeros(B, N, C, device="cuda")
+    want.view(-1, C).index_add_(0, (idx + torch.arange(B, device="cuda").view(B, 1, 1) * N).view(-1), g[:, :C].float())
+    torch.testing.assert_close(feat.grad.float(), want, rtol=2e-2, atol=2e-2)
+
+
+def _build(cls, *a, **kw):
+    torch.manual_seed(42)
+    return cls(*a, **kw).cuda()
+
+
+@pytest.mark.parametrize("name", ["pn2_ssg", "pn2_msg", "dgcnn"])
+def test_bf16_networks_track_fp32_networks(rm, name):
+    import bench
+    torch.manual_seed(3)
+    B, N = 2, (1024 if name == "dgcnn" else 2048)
+    xyz, colors, labels = bench.synthetic_batch(B, N, 5, "cuda")
+    res = {}
+    for mode in ("fp32", "bf16"):
+        torch.manual_seed(42)
+        model, cdim = bench.build_model(name)
+        model = model.cuda().train()
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.eval()
+        rm.set_precision(mode)
+        torch.manual_seed(9)
+        logits = model(xyz, colors)
+        loss = bench.loss_fn(logits, labels, cdim)
+        loss.backward()
+        rm.set_precision("fp32")
+        gn = torch.stack([p.grad.norm() for p in model.parameters() if p.grad is not None])
+        res[mode] = (logits.detach().float(), float(loss), gn)
+    l32, l16 = res["fp32"][0], res["bf16"][0]
+    assert l16.shape == l32.shape
+    # bf16 activations through ~20 layers; single points can move (arg-max / neighbour flips), the
+    # bulk must not
+    print(name, "mean rel", float((l16 - l32).abs().mean() / l32.abs().mean()),
+          "loss", res["bf16"][1], res["fp32"][1])
+    assert float((l16 - l32).abs().mean() / l32.abs().mean()) < 0.35
+    assert abs(res["bf16"][1] - res["fp32"][1]) < 0.02 * res["fp32"][1]
+    big = res["fp32"][2] > 1e-3 * res["fp32"][2].max()
+    assert float(((res["bf16"][2] - res["fp32"][2]).abs() / res["fp32"][2])[big].median()) < 0.05
+
+
+def test_bf16_training_reaches_fp32_miou(rm):
+    """Short training on a learnable synthetic task: mIoU (inference.py:814-855 definition) of the
+    bf16 mode within 5 points of the fp32 mode."""
+    from pointcloud_bridge_amd import train
+    from pointcloud_bridge_amd.models.containers import PointNet2
+    enc = [(256, 0.2, 16, 6, [32, 32, 64]), (64, 0.4, 16, 67, [64, 64, 128]), (16, 0.8, 16, 131, [128, 128, 256])]
+    data = train.synthetic_scenes(8, 1024, seed=0, device="cuda")
+    val = train.synthetic_scenes(4, 1024, seed=1, device="cuda")
+    miou = {}
+    for mode in ("fp32", "bf16"):
+        torch.manual_seed(42)
+        model = PointNet2(5, encoder=enc)
+        # decoder widths follow the encoder of this small variant
+        from pointcloud_bridge_amd.models.pointnet2_utils import FeaturePropagation
+        model.fp3 = FeaturePropagation(256 + 128, [128, 128])
+        model.fp2 = FeaturePropagation(128 + 64, [128, 64])
+        model.fp1 = FeaturePropagation(64, [128, 128, 128])
+        model = model.cuda()
+        rm.set_precision(mode)
+        tr = train.Trainer(model, 5, lr=2e-3)
+        torch.manual_seed(0)
+        for _ in range(60):
+            tr.train_step(data)
+        miou[mode] = tr.evaluate([val])["miou"]
+        rm.set_precision("fp32")
+    assert miou["fp32"] > 0.5, miou
+    assert abs(miou["bf16"] - miou["fp32"]) < 0.05, miou
