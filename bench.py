@@ -147,7 +147,8 @@ def main():
     fence()
     ops.kernel_timer_start(ROOFLINE_KERNEL)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ops.kernel_timer_enable(i % 5 == 0)  # HIP events around the roofline kernel on every 5th step
         loss = step()
     fence()
     dt = time.perf_counter() - t0
@@ -186,12 +187,12 @@ def main():
         dist.destroy_process_group()
 
 
-# Dominant HBM-bound kernel of the step and its algorithmic bytes per unit:
-# group_points writes one fp32 row of (3 + C) floats per (centroid, neighbour) pair and reads the
-# same amount plus one int64 index: 8 * (3 + C) + 8 bytes per grouped row... the unit is one
-# OUTPUT FLOAT (4 B written + 4 B read + 8/(3+C) B of index, counted as 8 B).
-ROOFLINE_KERNEL = "pcb_group_points"
-ROOFLINE_BYTES_PER_UNIT = 8.0
+# Dominant kernel of the step (profiles/): the fused bf16 row GEMM pcb_gemm_nt_bf16 (forward and
+# input-gradient GEMMs of every pointwise layer).  It is HBM-bound (skinny: K, N <= a few hundred).
+# Work unit = one algorithmic HBM byte: every activation operand read once and the output written
+# once, 2 B per bf16 element; the wrappers pass that count per launch.
+ROOFLINE_KERNEL = "pcb_gemm_nt_bf16"
+ROOFLINE_BYTES_PER_UNIT = 1.0
 
 if __name__ == "__main__":
     main()

@@ -168,6 +168,8 @@ struct Raw {
 // ---- gemm_nt ----------------------------------------------------------------------------------
 constexpr int NT_BM = 128, NT_BN = 128, NT_BK = 64;
 constexpr int NT_LD = NT_BK + 8;  // LDS row stride in bf16 (144 B): conflict-free ds_read_b128
+constexpr int NT_OUT_LD = NT_BN + 8;  // row stride of the per-wave output staging block (272 B)
+static_assert(4 * 32 * NT_OUT_LD <= (NT_BM + NT_BN) * NT_LD, "output staging must fit the stage buffers");
 
 template <int PRO, int STATS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
@@ -175,8 +177,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
                                                        float *__restrict__ sums)
 {
     const Operand A = local_copy(A_arg);
-    __shared__ __attribute__((aligned(16))) u16 As[NT_BM * NT_LD];
-    __shared__ __attribute__((aligned(16))) u16 Bs[NT_BN * NT_LD];
+    // one LDS array: [A stage | B stage] in the main loop, per-wave output staging in the epilogue
+    __shared__ __attribute__((aligned(16))) u16 smem[(NT_BM + NT_BN) * NT_LD];
+    u16 *const As = smem;
+    u16 *const Bs = smem + NT_BM * NT_LD;
     __shared__ float ssum[2 * NT_BN];
 
     const int t = threadIdx.x;
@@ -248,17 +252,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
         }
         __syncthreads();
         if (k0 + NT_BK >= K) {
-            // tile done.  C/D map of a 32x32 tile: col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*(lane >> 5)
+            // tile done.  C/D map of a 32x32 tile: col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*(lane >> 5).
+            // A lane owns single elements of many rows, so the tile goes through LDS once more: each
+            // wave parks its 32 x 128 bf16 block in its own slice of the (now idle) stage buffers
+            // and stores it back as 16-byte row segments -- 8 wide stores per lane instead of 64
+            // two-byte ones.
             const long m0 = tile * NT_BM;
+            u16 *const stage = smem + wave * (32 * NT_OUT_LD);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = n0 + j * 32 + (lane & 31);
                 float sv = 0.0f, sq = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const long r = m0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                     const u16 h = f2bf(acc[j][i]);
-                    if (r < R && n < N) out[r * N + n] = h;
+                    stage[rr * NT_OUT_LD + j * 32 + (lane & 31)] = h;
                     if (STATS) {
                         const float v = bf2f(h);  // statistics of the values the next kernels will read
                         sv += v;
@@ -271,6 +279,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
                     atomicAdd(&ssum[NT_BN + j * 32 + (lane & 31)], sq);
                 }
             }
+            // same wave wrote and reads its slice: a wave-level LDS fence is enough
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int ch = v * 64 + lane;     // 512 chunks of 8 columns: 32 rows x 16 chunks
+                const int rr = ch >> 4, cc = (ch & 15) * 8;
+                const long r = m0 + wave * 32 + rr;
+                const int n = n0 + cc;
+                if (r < R && n < N)
+                    *reinterpret_cast<uint4 *>(out + r * N + n) =
+                        *reinterpret_cast<const uint4 *>(&stage[rr * NT_OUT_LD + cc]);
+            }
+            __syncthreads();  // the next stage's LDS writes must not overtake another wave's read-back
         }
         if (!more) break;
         tile = ntile;

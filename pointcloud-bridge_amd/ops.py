@@ -26,7 +26,14 @@ _timer = None
 def kernel_timer_start(name):
     """Start recording (event pairs, work units) for every launch of C-ABI entry point `name`."""
     global _timer
-    _timer = {"name": name, "events": [], "units": 0}
+    _timer = {"name": name, "events": [], "units": 0, "on": True}
+
+
+def kernel_timer_enable(flag):
+    """Pause / resume event recording (bench.py samples one step in five: an event pair around every
+    launch costs microseconds of its own, which must not leak into the throughput figure)."""
+    if _timer is not None:
+        _timer["on"] = bool(flag)
 
 
 def kernel_timer_stop():
@@ -43,7 +50,7 @@ def _launch(name, units, *args):
     """Call entry point `name` of libpcb_hip.so on the current stream; raise on a bad status."""
     fn = getattr(_lib.load(), name)
     t = _timer
-    if t is not None and t["name"] == name:
+    if t is not None and t["on"] and t["name"] == name:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         status = fn(*args, _stream())

@@ -47,31 +47,36 @@ def shard_scenes(num_scenes, rank, world):
 class FlatGradAllReduce:
     """Averages the gradients of `params` across ranks with a single all-reduce.
 
-    The flat fp32 buffer is allocated once; every p.grad is made a view into it, so backward writes
-    straight into the bucket and no pack/unpack copy is needed."""
+    zero() drops the gradients (backward then writes fresh tensors: no accumulate kernels);
+    reduce() packs them into ONE flat fp32 buffer with one concatenation, all-reduces it once and
+    hands each parameter a view of the averaged buffer.  With a single rank both are no-ops."""
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        total = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
+        self.flat = None
         for p in self.params:
             if p.dtype != torch.float32:
                 raise TypeError("FlatGradAllReduce expects fp32 master parameters")
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def reduce(self):
         """Sum over ranks, divide by the world size (mean, as DDP does).  No-op for one rank."""
-        if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(self.world)
+        if self.world == 1:
+            return
+        live = [p for p in self.params if p.grad is not None]
+        self.flat = torch.cat([p.grad.reshape(-1) for p in live])
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.div_(self.world)
+        off = 0
+        for p in live:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
 
 
 def broadcast_parameters(module, src=0, group=None):

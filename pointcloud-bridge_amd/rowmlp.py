@@ -247,7 +247,7 @@ class _FusedStack(torch.autograd.Function):
                 y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
                 st = torch.zeros(10, C, dtype=torch.float32, device=dev)  # sums2|scale|shift|mean|invstd|bsums2|p|q
                 prev = stats[-1] if l else None
-                _launch("pcb_gemm_nt_bf16", R * C * cur_k, 1 if l else 0, cur.data_ptr(), 0,
+                _launch("pcb_gemm_nt_bf16", 2 * R * (cur_k + C), 1 if l else 0, cur.data_ptr(), 0,
                         prev[2].data_ptr() if l else 0, prev[3].data_ptr() if l else 0, 0, 0, 0, 0, 0, act,
                         wp.data_ptr(), R, C, cur_k, y.data_ptr(), st[0:2].data_ptr() if training else 0)
                 _launch("pcb_bn_finalize", C, st[0:2].data_ptr(), R, C,
@@ -316,19 +316,20 @@ class _FusedStack(torch.autograd.Function):
                 ws = torch.empty(_lib.load().pcb_gemm_tn_workspace(R, C, K), dtype=torch.float32, device=dev)
                 if l:
                     ps = stats[l - 1]
-                    _launch("pcb_gemm_tn_bf16", R * C * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                    _launch("pcb_gemm_tn_bf16", (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                             p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, 1,
                             ys[l - 1].data_ptr(), ps[2].data_ptr(), ps[3].data_ptr(), act, R, C, K, ws.data_ptr(),
                             dwp.data_ptr())
                 else:
-                    _launch("pcb_gemm_tn_bf16", R * C * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                    _launch("pcb_gemm_tn_bf16", (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                             p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, 0, x.data_ptr(), 0, 0,
                             0, R, C, K, ws.data_ptr(), dwp.data_ptr())
                 # input gradient: dz_{l-1} = dy . W   (skipped for the first layer if x needs none)
                 if l or ctx.needs_input_grad[0]:
                     wt = wp.t().contiguous()  # [K, C]: row n = input column, contiguous over C
                     dprev = torch.empty(R, K, dtype=torch.bfloat16, device=dev)
-                    _launch("pcb_gemm_nt_bf16", R * C * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                    # algorithmic bytes: y (+ dz, or dout/argmax per group) in, dz_{l-1} out
+                    _launch("pcb_gemm_nt_bf16", (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                             p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, wt.data_ptr(), R, K, C,
                             dprev.data_ptr(), 0)
                 else:
@@ -345,8 +346,8 @@ class _FusedStack(torch.autograd.Function):
                     grads[base + 1] = (torch.zeros(C, dtype=torch.float32, device=dev) if training
                                        else scale * bsums[0])
                 if has_affine[l]:
-                    grads[base + 2] = bsums[1].clone()
-                    grads[base + 3] = bsums[0].clone()
+                    grads[base + 2] = bsums[1]
+                    grads[base + 3] = bsums[0]
                 dz = dprev
         return (dz, None, None, None, None, *grads)
 
@@ -441,7 +442,7 @@ class _LinearBias(torch.autograd.Function):
         ws = torch.empty(lib.pcb_gemm_tn_workspace(R, npad, kp), dtype=torch.float32, device=dev)
         sums = torch.zeros(2, npad, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _launch("pcb_gemm_tn_bf16", R * npad * kp, 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
+            _launch("pcb_gemm_tn_bf16", 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
                     0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr())
             if has_bias:
                 _launch("pcb_colstats_bf16", R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
