@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default 16; dgcnn 8)")
     ap.add_argument("--npoints", type=int, default=None, help="points per scene (default 16384; dgcnn 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not overlap the next batch's FPS pyramid with the current backward pass")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (fp32 mode)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="pointwise-MLP arithmetic: bf16 activations (BASELINE config 2) or the fp32 parity mode")
@@ -128,9 +130,13 @@ def main():
     xyz, colors, labels = synthetic_batch(B, N, 1000 + rank, device)
     torch.manual_seed(7 + rank)  # CPU generator: FPS start indices
 
+    prefetch = (not args.no_prefetch) and hasattr(model, "prefetch")
+
     def step():
         bucket.zero()
         loss = loss_fn(model(xyz, colors), labels, cdim)
+        if prefetch:
+            model.prefetch(xyz)  # sampling pyramid of the next batch, concurrent with this backward
         loss.backward()
         bucket.reduce()
         opt.step()

@@ -178,13 +178,15 @@ int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream
 
 /*
  * BatchNorm bookkeeping of one layer: scale = gamma*invstd, shift = beta - mean*scale.
+ * `sums` is [nparts][2][C]: nparts partial (sum, sum of squares) slabs, added here in slab order
+ * (nparts = 1 after pcb_colstats_bf16, pcb_gemm_nt_partials(R,N) after pcb_gemm_nt_bf16).
  * training != 0: batch statistics from sums/rows, running_mean/var updated with `momentum`
  * (unbiased variance), `bias` (the conv bias the GEMM leaves out because it cancels inside a
  * train-mode BatchNorm) added to the mean that enters running_mean.  training == 0: running
  * statistics, bias folded into shift.  gamma/beta/bias/running_* may be NULL where unused.
  * mean/invstd [C] are outputs for the backward pass.
  */
-int pcb_bn_finalize(const float *sums, long rows, int C, const float *gamma, const float *beta,
+int pcb_bn_finalize(const float *sums, int nparts, long rows, int C, const float *gamma, const float *beta,
                     const float *bias, float *running_mean, float *running_var, float momentum,
                     float eps, int training, float *scale, float *shift, float *mean, float *invstd,
                     void *stream);
@@ -243,13 +245,17 @@ int pcb_group_rows_bf16_bwd(const void *grad_rows, const int64_t *idx, int B, in
  * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  scale/shift/p/q are fp32 [K].
  */
 
-/* out[R,N] (bf16) = A'[R,K] . w[N,K]^T, fp32 accumulation.  If sums != NULL, sums[0][n] and
- * sums[1][n] (fp32 [2,N], zeroed by the caller) receive the column sums / sums of squares of the
- * rounded outputs.  N % 8 == 0, K % 8 == 0. */
+/* out[R,N] (bf16) = A'[R,K] . w[N,K]^T, fp32 accumulation.  If sums != NULL it is a
+ * [pcb_gemm_nt_partials(R,N)][2][N] fp32 buffer: every workgroup stores the column sums / sums of
+ * squares of the rounded outputs it produced into its own slab (no atomics; pcb_bn_finalize adds
+ * the slabs).  N % 8 == 0, K % 8 == 0. */
 int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale, const float *shift,
                      const float *p, const float *q, const float *dout, const unsigned char *argmax,
                      int ns, int act, const void *w, long R, int N, int K, void *out, float *sums,
                      void *stream);
+
+/* Number of per-workgroup statistics slabs pcb_gemm_nt_bf16 writes for these sizes. */
+int pcb_gemm_nt_partials(long R, int N);
 
 /* dW[M,N] (fp32, overwritten) = A'[R,M]^T . B'[R,N].
  * A' = dz [R,M] itself (apro 0) or dy (apro 2 or 3, as above, built from dz|dout+argmax and y [R,M]);

@@ -24,6 +24,8 @@
 // accumulation in v_mfma_f32_32x32x16_bf16, and no intermediate tensor.  gemm_tn needs both
 // operands transposed (reduction index = row = slow memory axis): tiles are stored row-major as
 // loaded and read back with ds_read_b64_tr_b16 (hardware transpose read).
+#include <stdlib.h>
+
 #include "pcb_common.h"
 
 namespace {
@@ -113,8 +115,9 @@ template <int PRO>
 struct Raw {
     uint4 v0;                 // PLAIN/BNACT: rows; DY: dz
     uint4 v1;                 // DY / DY_POOL: y
-    float4 d0, d1;            // DY_POOL: dout
     unsigned long long arg;   // DY_POOL: packed arg-max bytes
+    const float *dptr;        // DY_POOL: this chunk's 8 dout values (read in finish(): the group's
+                              // dout row is shared by ns consecutive rows, so it sits in L1/L2)
     int j;                    // DY_POOL: row index inside its group
     bool live;
     __device__ __forceinline__ void load(const Operand &o, long r, int c, long rows, int cols)
@@ -130,8 +133,7 @@ struct Raw {
             const long g = rs / o.ns;
             j = (int)(rs - g * o.ns);
             arg = *reinterpret_cast<const unsigned long long *>(o.arg + g * cols + cs);
-            d0 = *reinterpret_cast<const float4 *>(o.dout + g * cols + cs);
-            d1 = *reinterpret_cast<const float4 *>(o.dout + g * cols + cs + 4);
+            dptr = o.dout + g * cols + cs;
         }
     }
     __device__ __forceinline__ uint4 finish(const Consts<PRO> &k, int act) const
@@ -151,6 +153,8 @@ struct Raw {
         if (PRO == PRO_DY) {
             unpack8(v0, f);
         } else {
+            const float4 d0 = *reinterpret_cast<const float4 *>(dptr);
+            const float4 d1 = *reinterpret_cast<const float4 *>(dptr + 4);
             const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] = ((int)((arg >> (8 * i)) & 0xff) == j) ? d[i] : 0.0f;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
     __shared__ __attribute__((aligned(16))) u16 smem[(NT_BM + NT_BN) * NT_LD];
     u16 *const As = smem;
     u16 *const Bs = smem + NT_BM * NT_LD;
-    __shared__ float ssum[2 * NT_BN];
+    __shared__ float ssum[4 * 2 * NT_BN];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -197,112 +201,129 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
     // across tile boundaries too.
     long tile = blockIdx.x;
     if (tile >= tiles_m) return;
-    int k0 = 0;
 
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
-    if (STATS) {
-        for (int i = t; i < 2 * NT_BN; i += 256) ssum[i] = 0.0f;
-    }
+    // statistics: each lane owns one output column per 32-wide tile for the whole kernel, so the
+    // column sums live in 8 registers and meet the other lanes/waves only once, at the very end
+    float st_s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, st_q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
     Raw<PRO> ra[4];
     Consts<PRO> ka;
     uint4 rb[4];
+    uint32_t keepb[4];
     auto fetch = [&](long tl, int kb) {
         const int kc = kb + chunk * 8;
         const long mb = tl * NT_BM;
-        ka.load(A, kc, K);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ra[i].load(A, mb + rrow + 32 * i, kc, R, K);
             const int n = n0 + rrow + 32 * i;
-            const uint4 w = *reinterpret_cast<const uint4 *>(Bw + (long)(n < N ? n : N - 1) * K + (kc < K ? kc : 0));
-            const uint32_t keep = (n < N && kc < K) ? 0xffffffffu : 0u;
-            rb[i] = make_uint4(w.x & keep, w.y & keep, w.z & keep, w.w & keep);
+            // raw load now, masking when the stage is written to LDS: touching the value here would
+            // make the wave wait for the load before it reaches the MFMAs
+            rb[i] = *reinterpret_cast<const uint4 *>(Bw + (long)(n < N ? n : N - 1) * K + (kc < K ? kc : 0));
+            keepb[i] = (n < N && kc < K) ? 0xffffffffu : 0u;
         }
     };
     fetch(tile, 0);
-    while (true) {
+    for (; tile < tiles_m; tile += gridDim.x) {
+        for (int k0 = 0; k0 < K; k0 += NT_BK) {
+            // per-column constants of this stage's chunk: L1/L2-resident, fetched here rather than
+            // with the prefetch so that they are not live across the MFMA section
+            ka.load(A, k0 + chunk * 8, K);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4 *>(&As[(rrow + 32 * i) * NT_LD + chunk * 8]) = ra[i].finish(ka, A.act);
-            *reinterpret_cast<uint4 *>(&Bs[(rrow + 32 * i) * NT_LD + chunk * 8]) = rb[i];
-        }
-        __syncthreads();
-        int nk = k0 + NT_BK;
-        long ntile = tile;
-        if (nk >= K) {
-            nk = 0;
-            ntile += gridDim.x;
-        }
-        const bool more = ntile < tiles_m;
-        if (more) fetch(ntile, nk);  // next stage's global loads fly under the MFMAs
-#pragma unroll
-        for (int ks = 0; ks < NT_BK / 16; ++ks) {
-            const int kk = ks * 16 + (lane >> 5) * 8;
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[(wave * 32 + (lane & 31)) * NT_LD + kk]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(j * 32 + (lane & 31)) * NT_LD + kk]);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<uint4 *>(&As[(rrow + 32 * i) * NT_LD + chunk * 8]) = ra[i].finish(ka, A.act);
+                *reinterpret_cast<uint4 *>(&Bs[(rrow + 32 * i) * NT_LD + chunk * 8]) =
+                    make_uint4(rb[i].x & keepb[i], rb[i].y & keepb[i], rb[i].z & keepb[i], rb[i].w & keepb[i]);
             }
-        }
-        __syncthreads();
-        if (k0 + NT_BK >= K) {
-            // tile done.  C/D map of a 32x32 tile: col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*(lane >> 5).
-            // A lane owns single elements of many rows, so the tile goes through LDS once more: each
-            // wave parks its 32 x 128 bf16 block in its own slice of the (now idle) stage buffers
-            // and stores it back as 16-byte row segments -- 8 wide stores per lane instead of 64
-            // two-byte ones.
-            const long m0 = tile * NT_BM;
-            u16 *const stage = smem + wave * (32 * NT_OUT_LD);
+            __syncthreads();
+            // next stage's global loads fly under the MFMAs, across the tile boundary too
+            // (ONE call site: two would double the live staging registers)
+            const bool last_k = k0 + NT_BK >= K;
+            const long ntile = last_k ? tile + gridDim.x : tile;
+            const int nk = last_k ? 0 : k0 + NT_BK;
+            if (ntile < tiles_m) fetch(ntile, nk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float sv = 0.0f, sq = 0.0f;
+            for (int ks = 0; ks < NT_BK / 16; ++ks) {
+                const int kk = ks * 16 + (lane >> 5) * 8;
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[(wave * 32 + (lane & 31)) * NT_LD + kk]);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                    const u16 h = f2bf(acc[j][i]);
-                    stage[rr * NT_OUT_LD + j * 32 + (lane & 31)] = h;
-                    if (STATS) {
-                        const float v = bf2f(h);  // statistics of the values the next kernels will read
-                        sv += v;
-                        sq = fmaf(v, v, sq);
-                    }
-                    acc[j][i] = 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(j * 32 + (lane & 31)) * NT_LD + kk]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
                 }
+            }
+            __syncthreads();
+        }
+        // tile done.  C/D map of a 32x32 tile: col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*(lane >> 5).
+        // A lane owns single elements of many rows, so the tile goes through LDS once more: each
+        // wave parks its 32 x 128 bf16 block in its own slice of the (now idle) stage buffers
+        // and stores it back as 16-byte row segments -- 8 wide stores per lane instead of 64
+        // two-byte ones.
+        const long m0 = tile * NT_BM;
+        u16 *const stage = smem + wave * (32 * NT_OUT_LD);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sv = 0.0f, sq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const u16 h = f2bf(acc[j][i]);
+                stage[rr * NT_OUT_LD + j * 32 + (lane & 31)] = h;
                 if (STATS) {
-                    atomicAdd(&ssum[j * 32 + (lane & 31)], sv);
-                    atomicAdd(&ssum[NT_BN + j * 32 + (lane & 31)], sq);
+                    const float v = bf2f(h);  // statistics of the values the next kernels will read
+                    sv += v;
+                    sq = fmaf(v, v, sq);
                 }
+                acc[j][i] = 0.0f;
             }
-            // same wave wrote and reads its slice: a wave-level LDS fence is enough
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-#pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                const int ch = v * 64 + lane;     // 512 chunks of 8 columns: 32 rows x 16 chunks
-                const int rr = ch >> 4, cc = (ch & 15) * 8;
-                const long r = m0 + wave * 32 + rr;
-                const int n = n0 + cc;
-                if (r < R && n < N)
-                    *reinterpret_cast<uint4 *>(out + r * N + n) =
-                        *reinterpret_cast<const uint4 *>(&stage[rr * NT_OUT_LD + cc]);
+            if (STATS) {
+                st_s[j] += sv;
+                st_q[j] += sq;
             }
-            __syncthreads();  // the next stage's LDS writes must not overtake another wave's read-back
         }
-        if (!more) break;
-        tile = ntile;
-        k0 = nk;
+        // same wave wrote and reads its slice: a wave-level LDS fence is enough
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int ch = v * 64 + lane;     // 512 chunks of 8 columns: 32 rows x 16 chunks
+            const int rr = ch >> 4, cc = (ch & 15) * 8;
+            const long r = m0 + wave * 32 + rr;
+            const int n = n0 + cc;
+            if (r < R && n < N)
+                *reinterpret_cast<uint4 *>(out + r * N + n) =
+                    *reinterpret_cast<const uint4 *>(&stage[rr * NT_OUT_LD + cc]);
+        }
+        __syncthreads();  // the next stage's LDS writes must not overtake another wave's read-back
     }
     if (STATS) {
+        // lanes l and l+32 hold the same column (different rows); then the 4 waves meet in LDS; the
+        // workgroup's totals go to ITS slot of the partials buffer (no atomics: pcb_bn_finalize sums
+        // the slots in a fixed order)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s2 = st_s[j] + __shfl_xor(st_s[j], 32);
+            const float q2 = st_q[j] + __shfl_xor(st_q[j], 32);
+            if (lane < 32) {
+                ssum[(wave * 2 + 0) * NT_BN + j * 32 + lane] = s2;
+                ssum[(wave * 2 + 1) * NT_BN + j * 32 + lane] = q2;
+            }
+        }
         __syncthreads();
         if (t < NT_BN && n0 + t < N) {
-            atomicAdd(&sums[n0 + t], ssum[t]);
-            atomicAdd(&sums[N + n0 + t], ssum[NT_BN + t]);
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                a += ssum[(w * 2 + 0) * NT_BN + t];
+                b += ssum[(w * 2 + 1) * NT_BN + t];
+            }
+            sums[((long)blockIdx.x * 2 + 0) * N + n0 + t] = a;
+            sums[((long)blockIdx.x * 2 + 1) * N + n0 + t] = b;
         }
     }
 }
@@ -459,7 +480,8 @@ void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, 
 {
     long tiles = (R + NT_BM - 1) / NT_BM;
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
-    const long resident = 512 / ny > 0 ? 512 / ny : 1;  // ~2 workgroups per CU in total, persistent over row tiles
+    static const long kResident = getenv("PCB_NT_RESIDENT") ? atol(getenv("PCB_NT_RESIDENT")) : 512;
+    const long resident = kResident / ny > 0 ? kResident / ny : 1;  // ~2 workgroups per CU in total, persistent over row tiles
     const dim3 grid((unsigned)(tiles < resident ? tiles : resident), ny);
     if (sums)
         hipLaunchKernelGGL((gemm_nt_kernel<PRO, 1>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums);
@@ -571,6 +593,16 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
     else
         launch_tn<PRO_DY_POOL>(A, B, bpro, R, M, N, workspace, dW, st);
     return pcb_check_launch();
+}
+
+extern "C" int pcb_gemm_nt_partials(long R, int N)
+{
+    if (R <= 0 || N <= 0) return 0;
+    const long tiles = (R + NT_BM - 1) / NT_BM;
+    const long ny = (N + NT_BN - 1) / NT_BN;
+    static const long kResident = getenv("PCB_NT_RESIDENT") ? atol(getenv("PCB_NT_RESIDENT")) : 512;
+    const long resident = kResident / ny > 0 ? kResident / ny : 1;
+    return (int)(tiles < resident ? tiles : resident);
 }
 
 extern "C" long pcb_gemm_tn_workspace(long R, int M, int N)

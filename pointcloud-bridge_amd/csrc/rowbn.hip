@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restr
 // torch.nn.BatchNorm does.  eval: running statistics; the bias is folded into the shift.
 // Outputs: scale = gamma*invstd, shift = beta - (mean_y)*scale [+ bias*scale in eval], and
 // mean_y / invstd for the backward pass.
-__global__ void bn_finalize_kernel(const float *__restrict__ sums, long rows, int C,
+__global__ void bn_finalize_kernel(const float *__restrict__ sums, int nparts, long rows, int C,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    const float *__restrict__ bias, float *__restrict__ running_mean,
                                    float *__restrict__ running_var, float momentum, float eps,
@@ -112,8 +112,13 @@ __global__ void bn_finalize_kernel(const float *__restrict__ sums, long rows, in
     float mean_y, invstd;
     if (training) {
         const float n = (float)rows;
-        mean_y = sums[c] / n;
-        float var = sums[C + c] / n - mean_y * mean_y;
+        float s1 = 0.0f, s2 = 0.0f;  // sums is [nparts][2][C]: per-workgroup partials, fixed order
+        for (int k = 0; k < nparts; ++k) {
+            s1 += sums[((long)k * 2 + 0) * C + c];
+            s2 += sums[((long)k * 2 + 1) * C + c];
+        }
+        mean_y = s1 / n;
+        float var = s2 / n - mean_y * mean_y;
         var = var < 0.0f ? 0.0f : var;
         invstd = rsqrtf(var + eps);
         if (running_mean) {
@@ -412,14 +417,14 @@ extern "C" int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, v
     return pcb_check_launch();
 }
 
-extern "C" int pcb_bn_finalize(const float *sums, long rows, int C, const float *gamma,
+extern "C" int pcb_bn_finalize(const float *sums, int nparts, long rows, int C, const float *gamma,
                                const float *beta, const float *bias, float *running_mean,
                                float *running_var, float momentum, float eps, int training,
                                float *scale, float *shift, float *mean, float *invstd, void *stream)
 {
     if (!scale || !shift || !mean || !invstd || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
-    if (training ? !sums : (!running_mean || !running_var)) return PCB_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
+    if (training ? (!sums || nparts < 1) : (!running_mean || !running_var)) return PCB_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, nparts,
                        rows, C, gamma, beta, bias, running_mean, running_var, momentum, eps, training,
                        scale, shift, mean, invstd);
     return pcb_check_launch();

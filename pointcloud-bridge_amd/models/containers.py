@@ -12,7 +12,15 @@ import torch.nn.functional as F
 
 from .. import rowmlp
 from .pointnet2_utils import (EnhancedFeaturePropagation, FeaturePropagation, MultiScaleSetAbstraction,
-                              SetAbstraction, _channels_last, _seq_rows)
+                              SetAbstraction, _channels_last, _seq_rows, prefetch_sampling)
+
+
+class _SamplingPrefetchMixin:
+    def prefetch(self, xyz):
+        """Start the FPS pyramid of the NEXT batch's coordinates on a side stream (see
+        pointnet2_utils.prefetch_sampling); call between forward and backward of the current batch."""
+        prefetch_sampling(xyz.contiguous(), [self.sa1.npoint, self.sa2.npoint, self.sa3.npoint])
+
 
 # (npoint, radius, nsample, in_channel, mlp) -- models/model.py:17-19 == models/pointnet2.py:20-22
 _SSG_ENCODER = [
@@ -28,7 +36,7 @@ _MSG_ENCODER = [
 ]
 
 
-class PointNet2(nn.Module):
+class PointNet2(_SamplingPrefetchMixin, nn.Module):
     """PointNet++ SSG segmentation net.
 
     rgb_skip=False: `PointNet2` of models/model.py:12-56 (fp1 sees only the propagated features).
@@ -90,7 +98,7 @@ class MultiScaleFeatureFusion(nn.Module):
         return torch.cat(outs, dim=2)
 
 
-class PointNet2MSG(nn.Module):
+class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):
     """PointNet++ MSG segmentation net = the SA/FP trunk of `EnhancedPointNet2` (BridgeSeg),
     models/model.py:58-147: MSG encoder (:73-76), EnhancedFeaturePropagation decoder (:84-86),
     MultiScaleFeatureFusion (:88-91) and the final_fusion head (:93-99).

@@ -40,8 +40,62 @@ def farthest_point_sample(xyz, npoint):
     Consumes exactly one torch.randint(0, N, (B,)) from the CPU default generator, like the
     reference (:69), so seeded runs sample the same start points."""
     B, N, _ = xyz.shape
-    start = torch.randint(0, N, (B,), dtype=torch.long).to(xyz.device)
+    ops._need_cuda(xyz)  # GPU only: fail here, before any staging copy
+    start = torch.randint(0, N, (B,), dtype=torch.long)
+    # pinned staging + asynchronous copy: a pageable .to(device) would stall the host until the
+    # stream has drained, three times per forward pass
+    start = start.pin_memory().to(xyz.device, non_blocking=True)
     return ops.furthest_point_sample(xyz, npoint, start)
+
+
+# ---------------------------------------------------------------------------------------------
+# sampling prefetch: FPS depends on the coordinates only (not on any weight), so the sampling pyramid
+# of the NEXT batch can run on a side stream (it occupies one CU per scene) while the current batch
+# is still in its backward pass -- the GPU-side counterpart of the reference's DataLoader workers
+# preparing the next batch (train_MulSca_PN2.py:92-106).  Results and RNG consumption are unchanged:
+# the start indices are drawn from the CPU generator in the same order, just earlier.
+# ---------------------------------------------------------------------------------------------
+_prefetched = {}
+_side_stream = None
+
+
+def _key(xyz, npoint):
+    return (xyz.data_ptr(), xyz._version, tuple(xyz.shape), int(npoint))
+
+
+def prefetch_sampling(xyz, npoints):
+    """Compute the FPS pyramid xyz -> npoints[0] -> npoints[1] -> ... on a side stream and park it
+    for the next forward pass over these coordinates (SetAbstraction / MultiScaleSetAbstraction pick
+    it up by tensor identity).  Call after the forward of the current batch."""
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream(device=xyz.device)
+    main = torch.cuda.current_stream()
+    _side_stream.wait_stream(main)
+    _prefetched.clear()
+    cur = xyz
+    with torch.cuda.stream(_side_stream):
+        for npoint in npoints:
+            idx = farthest_point_sample(cur, npoint)
+            new_xyz = index_points(cur, idx)
+            ev = torch.cuda.Event()
+            ev.record(_side_stream)
+            _prefetched[_key(cur, npoint)] = (idx, new_xyz, ev)
+            cur = new_xyz
+
+
+def _sample(xyz, npoint):
+    """(fps_idx, new_xyz) for this level: the prefetched pair if there is one, else computed now."""
+    hit = _prefetched.pop(_key(xyz, npoint), None)
+    if hit is None:
+        idx = farthest_point_sample(xyz, npoint)
+        return idx, index_points(xyz, idx)
+    idx, new_xyz, ev = hit
+    main = torch.cuda.current_stream()
+    main.wait_event(ev)
+    idx.record_stream(main)
+    new_xyz.record_stream(main)
+    return idx, new_xyz
 
 
 def query_ball_point(radius, nsample, xyz, new_xyz):
@@ -113,8 +167,7 @@ class SetAbstraction(nn.Module):
         """xyz [B,N,3], points [B,C,N] or None -> new_xyz [B,S,3], new_points [B,mlp[-1],S]."""
         feat = None if points is None else _channels_last(points)
         B = xyz.shape[0]
-        fps_idx = farthest_point_sample(xyz, self.npoint)
-        new_xyz = index_points(xyz, fps_idx)
+        _, new_xyz = _sample(xyz, self.npoint)
         idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
         rows, perm = rowmlp.group_rows(xyz, new_xyz, feat, idx)
         x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, rows, pool=self.nsample, perm=perm)
@@ -144,8 +197,7 @@ class MultiScaleSetAbstraction(nn.Module):
     def forward(self, xyz, points):
         """xyz [B,N,3], points [B,C,N] or None -> new_xyz [B,S,3], [B, len(radius)*mlp[-1], S]."""
         feat = None if points is None else _channels_last(points)
-        fps_idx = farthest_point_sample(xyz, self.npoint)  # one FPS for all scales (:335)
-        new_xyz = index_points(xyz, fps_idx)
+        _, new_xyz = _sample(xyz, self.npoint)  # one FPS for all scales (:335)
         if len(self.radius_list) == 2:
             idx_list = ops.ball_query2(self.radius_list, self.nsample_list, xyz, new_xyz)
         else:

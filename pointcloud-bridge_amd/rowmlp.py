@@ -131,7 +131,7 @@ class _LinearBNAct(torch.autograd.Function):
         with torch.cuda.device(dev):
             if training:
                 _launch("pcb_colstats_bf16", R * C, y.data_ptr(), R, C, sums.data_ptr())
-            _launch("pcb_bn_finalize", C, sums.data_ptr(), R, C,
+            _launch("pcb_bn_finalize", C, sums.data_ptr(), 1, R, C,
                     0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
                     0 if bias is None else bias.data_ptr(),
                     0 if running_mean is None else running_mean.data_ptr(),
@@ -240,6 +240,7 @@ class _FusedStack(torch.autograd.Function):
         layers = [flat[i * _FusedStack.NPER:(i + 1) * _FusedStack.NPER] for i in range(L)]
         ys, wps, stats = [], [], []
         cur, cur_k = x, x.shape[1]
+        lib = _lib.load()
         with torch.cuda.device(dev):
             for l, (w, bias, gamma, beta, rm, rv, training, momentum, eps) in enumerate(layers):
                 C = w.shape[0]
@@ -247,10 +248,12 @@ class _FusedStack(torch.autograd.Function):
                 y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
                 st = torch.zeros(10, C, dtype=torch.float32, device=dev)  # sums2|scale|shift|mean|invstd|bsums2|p|q
                 prev = stats[-1] if l else None
+                nparts = lib.pcb_gemm_nt_partials(R, C)
+                parts = torch.empty(nparts, 2, C, dtype=torch.float32, device=dev) if training else None
                 _launch("pcb_gemm_nt_bf16", 2 * R * (cur_k + C), 1 if l else 0, cur.data_ptr(), 0,
                         prev[2].data_ptr() if l else 0, prev[3].data_ptr() if l else 0, 0, 0, 0, 0, 0, act,
-                        wp.data_ptr(), R, C, cur_k, y.data_ptr(), st[0:2].data_ptr() if training else 0)
-                _launch("pcb_bn_finalize", C, st[0:2].data_ptr(), R, C,
+                        wp.data_ptr(), R, C, cur_k, y.data_ptr(), parts.data_ptr() if training else 0)
+                _launch("pcb_bn_finalize", C, parts.data_ptr() if training else 0, nparts, R, C,
                         0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
                         0 if bias is None else bias.data_ptr(), 0 if rm is None else rm.data_ptr(),
                         0 if rv is None else rv.data_ptr(), float(momentum), float(eps), int(training),

@@ -182,3 +182,24 @@ def test_dgcnn_logit_parity(k):
         assert np.mean(diff < REL) > 0.995, f"only {np.mean(diff < REL):.4f} of logits within 1e-4"
         assert diff.max() < 5e-2
     assert abs(loss - float(g[f"k{k}_loss"])) < 1e-3 * abs(float(g[f"k{k}_loss"]))
+
+
+def test_sampling_prefetch_gives_identical_results(mpu):
+    """The prefetched FPS pyramid (side stream, drawn earlier from the CPU generator) must reproduce
+    the inline result bit for bit, including the RNG stream."""
+    from pointcloud_bridge_amd.models.containers import PointNet2MSG
+    g = load_golden("model_pn2_msg")
+    model = build(PointNet2MSG, g["init_seed"], 5).eval()
+    xyz, colors = dev(g["xyz"]), dev(g["colors"])
+    with torch.no_grad():
+        torch.manual_seed(int(g["fwd_seed"]))
+        inline = model(xyz, colors)
+        after_inline = torch.rand(1)
+        torch.manual_seed(int(g["fwd_seed"]))
+        model.prefetch(xyz)
+        pre = model(xyz, colors)
+        after_pre = torch.rand(1)
+    assert torch.equal(inline, pre)
+    assert torch.equal(after_inline, after_pre)          # same number of CPU draws consumed
+    assert rel_err(pre, g["logits_eval"]) < REL
+    assert len(mpu._prefetched) == 0                     # every level was picked up
