@@ -99,24 +99,39 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restr
 // torch.nn.BatchNorm does.  eval: running statistics; the bias is folded into the shift.
 // Outputs: scale = gamma*invstd, shift = beta - (mean_y)*scale [+ bias*scale in eval], and
 // mean_y / invstd for the backward pass.
-__global__ void bn_finalize_kernel(const float *__restrict__ sums, int nparts, long rows, int C,
-                                   const float *__restrict__ gamma, const float *__restrict__ beta,
-                                   const float *__restrict__ bias, float *__restrict__ running_mean,
-                                   float *__restrict__ running_var, float momentum, float eps,
-                                   int training, float *__restrict__ scale, float *__restrict__ shift,
-                                   float *__restrict__ mean_out, float *__restrict__ invstd_out)
+// Block = 32 channels x 8 slab-lanes: the partial slabs are added by 8 lanes per channel (coalesced
+// 128-byte reads across the channels), combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float *__restrict__ sums, int nparts, long rows, int C, const float *__restrict__ gamma,
+    const float *__restrict__ beta, const float *__restrict__ bias, float *__restrict__ running_mean,
+    float *__restrict__ running_var, float momentum, float eps, int training, float *__restrict__ scale,
+    float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[2][8][32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s1 = 0.0f, s2 = 0.0f;
+    if (training && c < C) {
+        for (int k = pl; k < nparts; k += 8) {  // sums is [nparts][2][C]
+            s1 += sums[((long)k * 2 + 0) * C + c];
+            s2 += sums[((long)k * 2 + 1) * C + c];
+        }
+    }
+    red[0][pl][cl] = s1;
+    red[1][pl][cl] = s2;
+    __syncthreads();
+    if (pl != 0 || c >= C) return;
+    s1 = 0.0f;
+    s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s1 += red[0][k][cl];
+        s2 += red[1][k][cl];
+    }
     const float b = bias ? bias[c] : 0.0f;
     float mean_y, invstd;
     if (training) {
         const float n = (float)rows;
-        float s1 = 0.0f, s2 = 0.0f;  // sums is [nparts][2][C]: per-workgroup partials, fixed order
-        for (int k = 0; k < nparts; ++k) {
-            s1 += sums[((long)k * 2 + 0) * C + c];
-            s2 += sums[((long)k * 2 + 1) * C + c];
-        }
         mean_y = s1 / n;
         float var = s2 / n - mean_y * mean_y;
         var = var < 0.0f ? 0.0f : var;
@@ -424,7 +439,7 @@ extern "C" int pcb_bn_finalize(const float *sums, int nparts, long rows, int C, 
 {
     if (!scale || !shift || !mean || !invstd || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
     if (training ? (!sums || nparts < 1) : (!running_mean || !running_var)) return PCB_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, nparts,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, sums, nparts,
                        rows, C, gamma, beta, bias, running_mean, running_var, momentum, eps, training,
                        scale, shift, mean, invstd);
     return pcb_check_launch();
