@@ -166,6 +166,11 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
+        traffic = None  # HBM bytes per launch from the committed PMC passes of this same workload
+        pmc = os.path.join(REPO, "profiles", "r01_pmc_gemm_nt_bf16.json")
+        if args.model == "pn2_msg" and args.precision == "bf16" and os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"]
         alg_bytes = units * ROOFLINE_BYTES_PER_UNIT / max(launches, 1)  # per launch
         avg_s = kernel_ms / max(launches, 1) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if launches else 0.0
@@ -181,7 +186,7 @@ def main():
                        "scenes_per_gpu": B, "points_per_scene": N, "parallelism": f"dp{world} (scenes sharded)",
                        "loss": float(loss.detach())},
             "roofline": {"bound": "hbm", "kernel": ROOFLINE_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": launches, "avg_launch_us": avg_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
