@@ -175,7 +175,8 @@ def main():
         avg_s = kernel_ms / max(launches, 1) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if launches else 0.0
         out = {
-            "metric": "points/sec fwd+bwd, PointNet++ seg N=16384 B=16",
+            "metric": ("points/sec fwd+bwd, PointNet++ seg N=16384 B=16" if args.model != "dgcnn"
+                       else "points/sec fwd+bwd, DGCNN k=20 EdgeConv seg N=8192 B=8"),
             "value": world * B * N / (dt / args.steps),
             "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
