@@ -112,6 +112,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP kernels, no CPU fallback)")
+    local = local % torch.cuda.device_count()  # ranks may share a GPU in a gloo rehearsal
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -168,7 +169,8 @@ def main():
         ms = dt / args.steps * 1e3
         traffic = None  # HBM bytes per launch from the committed PMC passes of this same workload
         pmc = os.path.join(REPO, "profiles", "r01_pmc_gemm_nt_bf16.json")
-        if args.model == "pn2_msg" and args.precision == "bf16" and os.path.exists(pmc):
+        if (args.model == "pn2_msg" and args.precision == "bf16" and B == 16 and N == 16384
+                and os.path.exists(pmc)):
             with open(pmc) as f:
                 traffic = json.load(f)["traffic_bytes_per_launch"]
         alg_bytes = units * ROOFLINE_BYTES_PER_UNIT / max(launches, 1)  # per launch

@@ -91,9 +91,15 @@ class MultiScaleFeatureFusion(nn.Module):
             B, _, S = f.shape
             rows = _channels_last(f)
             if S != n:
-                ramp = torch.arange(S, dtype=torch.float32, device=f.device).view(1, 1, S)
-                src = F.interpolate(ramp, size=n).view(n).long()  # the very index map F.interpolate uses
-                rows = rows.index_select(1, src)
+                r = n // S
+                if n % S == 0 and (r & (r - 1)) == 0:
+                    # scale = S/n = 2^-j is exact in fp32: nearest source of point i is i // r, i.e.
+                    # every coarse row repeated r times (its backward is a plain sum over r rows)
+                    rows = rows.unsqueeze(2).expand(B, S, r, rows.shape[2]).reshape(B, n, rows.shape[2])
+                else:
+                    ramp = torch.arange(S, dtype=torch.float32, device=f.device).view(1, 1, S)
+                    src = F.interpolate(ramp, size=n).view(n).long()  # the very index map F.interpolate uses
+                    rows = rows.index_select(1, src)
             outs.append(_seq_rows(conv, rows.reshape(B * n, -1)).view(B, n, -1))
         return torch.cat(outs, dim=2)
 

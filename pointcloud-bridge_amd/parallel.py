@@ -26,7 +26,8 @@ def init_from_env(backend=None):
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # PCB_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)
+        backend = os.environ.get("PCB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():

@@ -23,3 +23,19 @@ def nt(pro, R, K, N, stats, ns=16):
 for args in [(0, 524288, 8, 64, 1), (1, 524288, 64, 64, 1), (1, 524288, 64, 128, 1), (2, 524288, 64, 64, 0), (2, 524288, 128, 64, 0),
              (3, 524288, 128, 64, 0), (2, 262144, 128, 264, 0), (2, 262144, 256, 264, 0), (1, 262144, 264, 128, 1), (0, 262144, 264, 128, 1)]:
     nt(*args)
+
+def tn(apro, bpro, R, M, N, ns=16):
+    dz = torch.randn(R, M, device="cuda").to(torch.bfloat16); y = torch.randn(R, M, device="cuda").to(torch.bfloat16)
+    xx = torch.randn(R, N, device="cuda").to(torch.bfloat16)
+    v = [torch.rand(M, device="cuda") for _ in range(4)]; xv = [torch.rand(N, device="cuda") for _ in range(2)]
+    dout = torch.randn(R // ns, M, device="cuda"); arg = torch.randint(0, ns, (R // ns, M), device="cuda", dtype=torch.uint8)
+    ws = torch.empty(L.pcb_gemm_tn_workspace(R, M, N), device="cuda"); dw = torch.empty(M, N, device="cuda")
+    f = lambda: L.pcb_gemm_tn_bf16(apro, dz.data_ptr(), y.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
+                                   dout.data_ptr(), arg.data_ptr(), ns, 1, bpro, xx.data_ptr(), xv[0].data_ptr(), xv[1].data_ptr(), 1, R, M, N,
+                                   ws.data_ptr(), dw.data_ptr(), st())
+    us = timeit(f)
+    byt = 2 * R * N + (2 * R * M if apro == 0 else 4 * R * M if apro == 2 else 2 * R * M + 5 * (R // ns) * M)
+    print(f"tn apro={apro} bpro={bpro} R={R} M={M} N={N}: {us:8.1f} us  {byt / us / 1e6:6.2f} TB/s  ws={ws.numel()*4/1e6:.1f}MB")
+for args in [(2, 0, 524288, 64, 8), (2, 1, 524288, 64, 64), (3, 1, 524288, 128, 64), (2, 0, 262144, 128, 264), (2, 1, 262144, 128, 128),
+             (3, 1, 262144, 256, 128), (2, 1, 262144, 128, 256), (2, 0, 262144, 256, 264), (0, 0, 262144, 264, 64)]:
+    tn(*args)
