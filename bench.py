@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not overlap the next batch's FPS pyramid with the current backward pass")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (fp32 mode)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train: fwd+loss+bwd+all-reduce+Adam (the headline metric); infer: eval-mode forward only, "
+                         "the reference's own published metric (eva_model.py:137-168, model_performance_comparison.csv)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="pointwise-MLP arithmetic: bf16 activations (BASELINE config 2) or the fp32 parity mode")
     args = ap.parse_args()
@@ -133,7 +136,7 @@ def main():
 
     prefetch = (not args.no_prefetch) and hasattr(model, "prefetch")
 
-    def step():
+    def train_step():
         bucket.zero()
         loss = loss_fn(model(xyz, colors), labels, cdim)
         if prefetch:
@@ -142,6 +145,14 @@ def main():
         bucket.reduce()
         opt.step()
         return loss
+
+    def infer_step():
+        with torch.no_grad():
+            return loss_fn(model(xyz, colors), labels, cdim)
+
+    if args.mode == "infer":
+        model.eval()
+    step = train_step if args.mode == "train" else infer_step
 
     def fence():
         torch.cuda.synchronize()
@@ -167,6 +178,13 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
+        # BASELINE.md publishes one number on this path that a bench mode reproduces exactly:
+        # PointNet2 (SSG) inference, B=4 x N=4096, fp32, eval, 1 GPU (RTX 4090): 35 557 pts/s
+        # (Highway_bridge/model_performance_comparison.csv:4).  The headline fwd+bwd metric has none.
+        vs_baseline = None
+        if (args.mode == "infer" and args.model == "pn2_ssg" and B == 4 and N == 4096
+                and args.precision == "fp32" and world == 1):
+            vs_baseline = (B * N / (dt / args.steps)) / 35557.0
         traffic = None  # HBM bytes per launch from the committed PMC passes of this same workload
         pmc = os.path.join(REPO, "profiles", "r01_pmc_gemm_nt_bf16.json")
         if (args.model == "pn2_msg" and args.precision == "bf16" and B == 16 and N == 16384
@@ -177,14 +195,14 @@ def main():
         avg_s = kernel_ms / max(launches, 1) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if launches else 0.0
         out = {
-            "metric": ("points/sec fwd+bwd, PointNet++ seg N=16384 B=16" if args.model != "dgcnn"
-                       else "points/sec fwd+bwd, DGCNN k=20 EdgeConv seg N=8192 B=8"),
+            "metric": (("points/sec fwd+bwd, " if args.mode == "train" else "points/sec inference (eval forward), ")
+                       + (f"PointNet++ seg N={N} B={B}" if args.model != "dgcnn" else f"DGCNN k=20 EdgeConv seg N={N} B={B}")),
             "value": world * B * N / (dt / args.steps),
             "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} fwd+CE+bwd+grad-allreduce+Adam, B={B} scenes/GPU x N={N} pts, "
+            "vs_baseline": vs_baseline, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} {'fwd+CE+bwd+grad-allreduce+Adam' if args.mode == 'train' else 'eval-mode forward+CE'}, B={B} scenes/GPU x N={N} pts, "
                                    f"unit-ball clouds (configs[1] of BASELINE.json)",
                        "scenes_per_gpu": B, "points_per_scene": N, "parallelism": f"dp{world} (scenes sharded)",
                        "loss": float(loss.detach())},
