@@ -328,6 +328,111 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
     }
 }
 
+// ---- gemm_nt with the transformed A tile resident in LDS -------------------------------------
+// For the input-gradient GEMMs whose output is wider than one 128-column tile (N = 264: the layers
+// fed by grouped / concatenated rows) the plain kernel would rebuild A' = dy(dz, y) once per column
+// tile.  Here a workgroup builds the 64 x K tile of A' once (K <= 256), keeps it in LDS and walks
+// the column tiles itself; only the weight stages (L2-resident) move through the register pipeline.
+constexpr int AR_BM = 64, AR_BN = 128, AR_BK = 64;
+constexpr int AR_BLD = AR_BK + 8;
+constexpr int AR_OLD = 64 + 8;  // per-wave output staging: 32 rows x 64 columns
+
+template <int PRO, int KCH>  // KCH = K/8 chunks per row held in LDS: 16 (K <= 128) or 32 (K <= 256)
+__global__ __launch_bounds__(256) void gemm_nt_ares_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
+                                                            int N, int K, u16 *__restrict__ out)
+{
+    const Operand A = local_copy(A_arg);
+    constexpr int ALD = KCH * 8 + 8;      // A row stride in bf16: rows 16 B apart in bank space
+    constexpr int RPT = 256 / KCH;        // rows covered by one pass of the 256 threads
+    __shared__ __attribute__((aligned(16))) u16 As[AR_BM * ALD];
+    __shared__ __attribute__((aligned(16))) u16 Bs[AR_BN * AR_BLD];
+    __shared__ __attribute__((aligned(16))) u16 Os[4 * 32 * AR_OLD];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves: 32 rows x 64 columns each
+    const long tiles_m = (R + AR_BM - 1) / AR_BM;
+    const int n_tiles = (N + AR_BN - 1) / AR_BN;
+    const int bchunk = t & 7, brow = t >> 3;
+
+    uint4 rb[4];
+    uint32_t keepb[4];
+    auto fetch_b = [&](int nt, int k0) {
+        const int kc = k0 + bchunk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nt * AR_BN + brow + 32 * i;
+            rb[i] = *reinterpret_cast<const uint4 *>(Bw + (long)(n < N ? n : N - 1) * K + (kc < K ? kc : 0));
+            keepb[i] = (n < N && kc < K) ? 0xffffffffu : 0u;
+        }
+    };
+
+    for (long tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
+        const long m0 = tile * AR_BM;
+        {   // phase 1: the whole transformed A tile, once
+            const int kc = (t % KCH) * 8;
+            Consts<PRO> ka;
+            ka.load(A, kc, K);
+            Raw<PRO> ra[AR_BM / RPT];
+#pragma unroll
+            for (int i = 0; i < AR_BM / RPT; ++i) ra[i].load(A, m0 + t / KCH + RPT * i, kc, R, K);
+#pragma unroll
+            for (int i = 0; i < AR_BM / RPT; ++i)
+                *reinterpret_cast<uint4 *>(&As[(t / KCH + RPT * i) * ALD + kc]) = ra[i].finish(ka, A.act);
+        }
+        fetch_b(0, 0);
+        __syncthreads();
+        for (int nt = 0; nt < n_tiles; ++nt) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+            for (int k0 = 0; k0 < K; k0 += AR_BK) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<uint4 *>(&Bs[(brow + 32 * i) * AR_BLD + bchunk * 8]) =
+                        make_uint4(rb[i].x & keepb[i], rb[i].y & keepb[i], rb[i].z & keepb[i], rb[i].w & keepb[i]);
+                __syncthreads();
+                const bool last_k = k0 + AR_BK >= K;
+                const int nnt = last_k ? nt + 1 : nt;
+                if (nnt < n_tiles) fetch_b(nnt, last_k ? 0 : k0 + AR_BK);
+#pragma unroll
+                for (int ks = 0; ks < AR_BK / 16; ++ks) {
+                    const int kk = ks * 16 + (lane >> 5) * 8;
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[(wm * 32 + (lane & 31)) * ALD + k0 + kk]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(wn * 64 + j * 32 + (lane & 31)) * AR_BLD + kk]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+            // column tile done: 16-byte row-segment stores through the wave's staging block
+            u16 *const stage = Os + wave * (32 * AR_OLD);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    stage[((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * AR_OLD + j * 32 + (lane & 31)] = f2bf(acc[j][i]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = v * 64 + lane;  // 256 chunks: 32 rows x 8 chunks of 8 columns
+                const int rr = ch >> 3, cc = (ch & 7) * 8;
+                const long r = m0 + wm * 32 + rr;
+                const int n = nt * AR_BN + wn * 64 + cc;
+                if (r < R && n < N)
+                    *reinterpret_cast<uint4 *>(out + r * N + n) = *reinterpret_cast<const uint4 *>(&stage[rr * AR_OLD + cc]);
+            }
+        }
+        __syncthreads();  // As is rebuilt for the next row tile
+    }
+}
+
 // ---- gemm_tn (weight gradient) ----------------------------------------------------------------
 constexpr int TN_BM = 128, TN_BN = 128, TN_RS = 32;  // RS rows of the reduction per stage
 constexpr int TN_LD = 128 + 32;                       // row stride 320 B: conflict-free tr reads
@@ -561,6 +666,23 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
     if (pro == PRO_DY_POOL && (!dout || !argmax || ns <= 0 || ns > 255)) return PCB_ERR_INVALID_ARG;
     const Operand A = make_operand(a0, a1, K, scale, shift, p, q, dout, argmax, ns, act);
     hipStream_t st = (hipStream_t)stream;
+    if (pro >= PRO_DY && !sums && N > NT_BN && K <= 256) {
+        // wide input gradient: transformed A tile resident in LDS, column tiles walked inside
+        const long tiles = (R + AR_BM - 1) / AR_BM;
+        const dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
+        if (pro == PRO_DY) {
+            if (K <= 128)
+                hipLaunchKernelGGL((gemm_nt_ares_kernel<PRO_DY, 16>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out);
+            else
+                hipLaunchKernelGGL((gemm_nt_ares_kernel<PRO_DY, 32>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out);
+        } else {
+            if (K <= 128)
+                hipLaunchKernelGGL((gemm_nt_ares_kernel<PRO_DY_POOL, 16>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out);
+            else
+                hipLaunchKernelGGL((gemm_nt_ares_kernel<PRO_DY_POOL, 32>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out);
+        }
+        return pcb_check_launch();
+    }
     switch (pro) {
         case PRO_PLAIN: launch_nt<PRO_PLAIN>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
         case PRO_BNACT: launch_nt<PRO_BNACT>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;

@@ -59,7 +59,8 @@ def _close(a, b, tol):
 
 @pytest.mark.parametrize("engine", ["fused", "staged"])
 @pytest.mark.parametrize("R,K,C,act,pool", [(4096, 8, 64, 1, 0), (2048, 264, 128, 1, 16), (1536, 128, 64, 2, 8),
-                                            (999 * 4, 72, 256, 0, 0), (640, 520, 512, 1, 32), (77 * 3, 16, 24, 1, 3)])
+                                            (999 * 4, 72, 256, 0, 0), (640, 520, 512, 1, 32), (77 * 3, 16, 24, 1, 3),
+                                            (1024, 264, 256, 1, 8), (1000, 264, 256, 2, 0)])
 def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, engine, R, K, C, act, pool):
     torch.manual_seed(R + C)
     dev = "cuda"
@@ -105,7 +106,7 @@ def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, engine, R, K, C, act, 
 
 @pytest.mark.parametrize("R,K,widths,act,pool,perm", [(2048, 8, [64, 64, 128], 1, 16, 0), (1024, 264, [128, 128, 256], 1, 32, 0),
                                                       (3000, 72, [256, 128], 1, 0, 0), (1280, 128, [64], 2, 20, 0),
-                                                      (1536, 24, [32, 32, 64], 1, 8, 16)])
+                                                      (1536, 24, [32, 32, 64], 1, 8, 16), (1100, 264, [256, 256], 1, 0, 0)])
 def test_fused_stack_forward_backward_vs_torch_fp32(rm, R, K, widths, act, pool, perm):
     """Multi-layer stack: BatchNorm+activation applied on operand load, statistics from the GEMM
     epilogue, dy recomputed on load in both backward GEMMs -- against a plain fp32 torch stack."""
