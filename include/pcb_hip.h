@@ -287,6 +287,30 @@ int pcb_bn_act_max_bwd_reduce_bf16(const float *dout, const unsigned char *argma
                                    const float *invstd, long groups, int ns, int C, int act, float *sums,
                                    void *stream);
 
+/*
+ * bf16 interpolation written straight into the row buffer of the following GEMM
+ * (FeaturePropagation.forward, models/pointnet2_utils.py:191-203: interpolate + concatenate):
+ * out[(b,n)][col0 .. col0+C) = sum_k w_k * feat[b, idx[b,n,k], :], w as in pcb_interpolate.
+ * feat [B,S,C] bf16, out [B*N, ld] bf16, C/ld/col0 multiples of 8, out_w [B,N,k] fp32 (optional).
+ */
+int pcb_interpolate_bf16(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C,
+                         int k, void *out, int ld, int col0, float *out_w, void *stream);
+
+/*
+ * Backward of the interpolation without atomics: an inverted index of the (n,q) pairs by target
+ * s (counting sort: pcb_interp_csr_count -> prefix sum by the caller -> pcb_interp_csr_fill), then
+ * one wave per target sums its contribution rows (pcb_interpolate_bwd_csr_bf16).
+ *   count/cursor [B*S] int32 zeroed by the caller; offsets [B*S+1] int64 = exclusive prefix sum of
+ *   count; entries [B*N*k] int32; grad_rows [B*N, ld] bf16 (columns col0..col0+C); w [B,N,k] fp32;
+ *   grad_feat [B,S,C] bf16 (overwritten).
+ */
+int pcb_interp_csr_count(const int64_t *idx, int B, int N, int S, int k, int *count, void *stream);
+int pcb_interp_csr_fill(const int64_t *idx, int B, int N, int S, int k, const long *offsets, int *cursor,
+                        int *entries, void *stream);
+int pcb_interpolate_bwd_csr_bf16(const void *grad_rows, int ld, int col0, const float *w, const long *offsets,
+                                 const int *entries, int B, int N, int S, int C, int k, void *grad_feat,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,10 @@ SIGNATURES = {
     "pcb_bn_act_max_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
     "pcb_group_rows_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "pcb_group_rows_bf16_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_interpolate_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
+    "pcb_interp_csr_count": [_p, _i, _i, _i, _i, _p, _p],
+    "pcb_interp_csr_fill": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
+    "pcb_interpolate_bwd_csr_bf16": [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "pcb_gemm_nt_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p],
     "pcb_gemm_tn_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _p],
     "pcb_gemm_tn_workspace": [_l, _i, _i],

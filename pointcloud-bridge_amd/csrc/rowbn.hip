@@ -99,20 +99,20 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restr
 // torch.nn.BatchNorm does.  eval: running statistics; the bias is folded into the shift.
 // Outputs: scale = gamma*invstd, shift = beta - (mean_y)*scale [+ bias*scale in eval], and
 // mean_y / invstd for the backward pass.
-// Block = 32 channels x 8 slab-lanes: the partial slabs are added by 8 lanes per channel (coalesced
-// 128-byte reads across the channels), combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+// Block = 32 channels x 32 slab-lanes: the partial slabs are added by 32 lanes per channel
+// (coalesced 128-byte reads across the channels), combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float *__restrict__ sums, int nparts, long rows, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ bias, float *__restrict__ running_mean,
     float *__restrict__ running_var, float momentum, float eps, int training, float *__restrict__ scale,
     float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out)
 {
-    __shared__ float red[2][8][32];
+    __shared__ float red[2][32][32];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s1 = 0.0f, s2 = 0.0f;
     if (training && c < C) {
-        for (int k = pl; k < nparts; k += 8) {  // sums is [nparts][2][C]
+        for (int k = pl; k < nparts; k += 32) {  // sums is [nparts][2][C]
             s1 += sums[((long)k * 2 + 0) * C + c];
             s2 += sums[((long)k * 2 + 1) * C + c];
         }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     s1 = 0.0f;
     s2 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 32; ++k) {
         s1 += red[0][k][cl];
         s2 += red[1][k][cl];
     }
@@ -439,7 +439,7 @@ extern "C" int pcb_bn_finalize(const float *sums, int nparts, long rows, int C, 
 {
     if (!scale || !shift || !mean || !invstd || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
     if (training ? (!sums || nparts < 1) : (!running_mean || !running_var)) return PCB_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, sums, nparts,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, nparts,
                        rows, C, gamma, beta, bias, running_mean, running_var, momentum, eps, training,
                        scale, shift, mean, invstd);
     return pcb_check_launch();

@@ -227,6 +227,21 @@ def _interpolate(xyz1, xyz2, points2, k):
     return out.to(feat.dtype)
 
 
+def _propagate_rows(xyz1, xyz2, points1, points2, k):
+    """Rows [B*N, *] = cat([points1, interpolate(points2)]) (skip features FIRST, reference :201 / :272)
+    plus the column-layout code `perm` of rowmlp (0 = reference order)."""
+    B, N, _ = xyz1.shape
+    S, C = xyz2.shape[1], points2.shape[1]
+    if rowmlp.is_bf16() and S > 1 and C % 8 == 0:
+        d2, idx = ops.three_nn(xyz1, xyz2, k)
+        skip = None if points1 is None else _channels_last(points1).reshape(B * N, -1)
+        return rowmlp.interpolate_concat(skip, _channels_last(points2), d2, idx)
+    x = _interpolate(xyz1, xyz2, points2, k)
+    if points1 is not None:
+        x = torch.cat([_channels_last(points1).to(x.dtype), x], dim=-1)
+    return x.reshape(B * N, -1), 0
+
+
 class FeaturePropagation(nn.Module):
     """3-NN inverse-distance feature propagation (reference :159-211)."""
 
@@ -242,10 +257,8 @@ class FeaturePropagation(nn.Module):
     def forward(self, xyz1, xyz2, points1, points2):
         """xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,D1,N] or None, points2 [B,D2,S] -> [B,mlp[-1],N]."""
         B, N, _ = xyz1.shape
-        x = _interpolate(xyz1, xyz2, points2, 3)
-        if points1 is not None:
-            x = torch.cat([_channels_last(points1).to(x.dtype), x], dim=-1)  # skip features FIRST (:201)
-        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x.reshape(B * N, -1))
+        x, perm = _propagate_rows(xyz1, xyz2, points1, points2, 3)
+        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x, perm=perm)
         return x.view(B, N, -1).transpose(1, 2)
 
 
@@ -275,14 +288,13 @@ class EnhancedFeaturePropagation(nn.Module):
 
     def forward(self, xyz1, xyz2, points1, points2):
         B, N, _ = xyz1.shape
-        x = _interpolate(xyz1, xyz2, points2, 4)
-        if points1 is not None:
-            x = torch.cat([_channels_last(points1).to(x.dtype), x], dim=-1)
-        x = x.reshape(B * N, -1)
-        x = x * _seq_rows(self.attention, x)                       # :279-280
+        x, perm = _propagate_rows(xyz1, xyz2, points1, points2, 4)
+        att = self.attention                                        # :279-280
+        a = rowmlp.conv_bn_act(att[0], att[1], x, rowmlp.ACT_RELU, perm=perm)
+        x = x * torch.sigmoid(rowmlp.conv_rows(att[3], a, out_gap=-perm))
         edge = _seq_rows(self.boundary_aware, xyz1.reshape(B * N, 3))  # :283
         identity = x
-        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x)
+        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x, perm=perm)
         if self.skip_connection:
             x = x + identity                                        # :292-293
         x = x + edge                                                # :296

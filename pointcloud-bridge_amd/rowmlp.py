@@ -177,11 +177,7 @@ class _LinearBNAct(torch.autograd.Function):
         dx = torch.mm(dy, wp) if ctx.needs_input_grad[0] else None
         dwp = _mm_f32out(dy.t(), x)  # [C, Kp]
         cout, k = wshape[0], wshape[1]
-        if perm > 0:
-            dw = torch.cat([dwp[:, perm:perm + 3], dwp[:, :perm]], dim=1)
-        else:
-            dw = dwp[:, :k]
-        dw = dw.reshape(wshape)
+        dw = _unpad_weight_grad(dwp, k, perm).reshape(wshape)
         # d(bias): sum of dy over rows -- exactly zero under batch statistics, scale*s1 otherwise
         dbias = None
         if has_bias:
@@ -192,16 +188,36 @@ class _LinearBNAct(torch.autograd.Function):
 
 
 def padded_weight_from(weight, kp, perm):
-    """Same as padded_weight but from the raw weight tensor ([Cout, K] or [Cout, K, 1(,1)])."""
+    """[Cout, kp] bf16 copy of a 1x1 conv weight ([Cout, K] or [Cout, K, 1(,1)]) in the column
+    layout of the bf16 row buffer it multiplies:
+      perm == 0  reference order, zero padded to kp
+      perm = C > 0   grouped rows of pcb_group_rows_bf16: the C feature columns first, then the 3
+                 centred coordinates (reference: coordinates first, :56/:347)
+      perm = -D < 0  interpolate+concat rows of interpolate_concat: the first D (skip) columns stay
+                 in place, the rest start at column pad8(D)"""
     w = weight.reshape(weight.shape[0], -1)
     cout, k = w.shape
     wp = torch.zeros(cout, kp, dtype=torch.bfloat16, device=w.device)
     if perm > 0:
         wp[:, :perm] = w[:, 3:3 + perm]
         wp[:, perm:perm + 3] = w[:, :3]
+    elif perm < 0:
+        d, dp = -perm, pad8(-perm)
+        wp[:, :d] = w[:, :d]
+        wp[:, dp:dp + k - d] = w[:, d:]
     else:
         wp[:, :k] = w
     return wp
+
+
+def _unpad_weight_grad(dwp, k, perm):
+    """Inverse of padded_weight_from's column layout for the weight gradient [Cout, kp] -> [Cout, k]."""
+    if perm > 0:
+        return torch.cat([dwp[:, perm:perm + 3], dwp[:, :perm]], dim=1)
+    if perm < 0:
+        d, dp = -perm, pad8(-perm)
+        return torch.cat([dwp[:, :d], dwp[:, dp:dp + k - d]], dim=1)
+    return dwp[:, :k]
 
 
 def _bn_bookkeeping(bn):
@@ -339,10 +355,7 @@ class _FusedStack(torch.autograd.Function):
                     dprev = None
                 # parameter gradients of this layer
                 k = wshapes[l][1]
-                if l == 0 and perm > 0:
-                    dw = torch.cat([dwp[:, perm:perm + 3], dwp[:, :perm]], dim=1)
-                else:
-                    dw = dwp[:, :k]
+                dw = _unpad_weight_grad(dwp, k, perm if l == 0 else 0)
                 base = l * _FusedStack.NPER
                 grads[base + 0] = dw.reshape(wshapes[l])
                 if has_bias[l]:
@@ -360,7 +373,7 @@ def _stack_fusable(convs, bns):
 
 
 def _fused_stack(convs, bns, x, act, pool, perm):
-    kp = x.shape[1] if perm > 0 else pad8(convs[0].in_channels)
+    kp = x.shape[1] if perm != 0 else pad8(convs[0].in_channels)
     xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
     flat = []
     for conv, bn in zip(convs, bns):
@@ -399,7 +412,7 @@ def conv_bn_act(conv, bn, x, act=ACT_RELU, pool=0, perm=0):
         return y
     if _ENGINE == "fused":
         return _fused_stack([conv], [bn], x, act, pool, perm)
-    kp = x.shape[1] if perm > 0 else pad8(conv.in_channels)
+    kp = x.shape[1] if perm != 0 else pad8(conv.in_channels)
     xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
     momentum = _bn_bookkeeping(bn)
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
@@ -417,28 +430,44 @@ class _LinearBias(torch.autograd.Function):
     ATen's strided bf16 reduction."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, out_gap):
+        """out_gap = D > 0: the output keeps the interpolate_concat column layout (first D outputs
+        in place, the rest from column pad8(D); untouched columns are exactly zero) and is returned
+        with all its padded columns; out_gap = 0: plain [R, n] output."""
         w = weight.reshape(weight.shape[0], -1)
         n, k = w.shape
-        npad, kp = pad8(n), x.shape[1]
+        kp = x.shape[1]
+        if out_gap:
+            d, dp = out_gap, pad8(out_gap)
+            npad = pad8(dp + n - d)
+            rows = torch.cat([torch.arange(d, device=x.device), dp + torch.arange(n - d, device=x.device)])
+        else:
+            npad = pad8(n)
+            rows = None
         wp = torch.zeros(npad, kp, dtype=torch.bfloat16, device=x.device)
-        wp[:n, :k] = w
-        y = torch.mm(x, wp.t())
-        if bias is not None:
-            y[:, :n] += bias.to(torch.bfloat16)
-        ctx.save_for_backward(x, wp)
+        bp = torch.zeros(npad, dtype=torch.bfloat16, device=x.device)
+        if rows is None:
+            wp[:n, :k] = w
+            if bias is not None:
+                bp[:n] = bias
+        else:
+            wp[rows, :k] = w.to(torch.bfloat16)
+            if bias is not None:
+                bp[rows] = bias.to(torch.bfloat16)
+        y = torch.addmm(bp, x, wp.t())
+        ctx.save_for_backward(x, wp, rows)
         ctx.cfg = (weight.shape, n, k, bias is not None)
-        return y[:, :n]
+        return y if out_gap else y[:, :n]
 
     @staticmethod
     def backward(ctx, g):
-        x, wp = ctx.saved_tensors
+        x, wp, rows = ctx.saved_tensors
         wshape, n, k, has_bias = ctx.cfg
         npad, kp = wp.shape
         R = x.shape[0]
         dev = x.device
         gy = g.to(torch.bfloat16)
-        gy = gy.contiguous() if npad == n else F.pad(gy, (0, npad - n))
+        gy = gy.contiguous() if gy.shape[1] == npad else F.pad(gy, (0, npad - gy.shape[1]))
         dx = torch.mm(gy, wp) if ctx.needs_input_grad[0] else None
         dw = torch.empty(npad, kp, dtype=torch.float32, device=dev)
         lib = _lib.load()
@@ -449,16 +478,77 @@ class _LinearBias(torch.autograd.Function):
                     0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr())
             if has_bias:
                 _launch("pcb_colstats_bf16", R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
-        return dx, dw[:n, :k].reshape(wshape), (sums[0, :n].clone() if has_bias else None)
+        if rows is None:
+            return dx, dw[:n, :k].reshape(wshape), (sums[0, :n].clone() if has_bias else None), None
+        return dx, dw[rows, :k].reshape(wshape), (sums[0, rows] if has_bias else None), None
 
 
-def conv_rows(conv, x, out_dtype=None):
-    """Plain 1x1 conv (with bias) on rows, no BatchNorm.  bf16 mode computes in bf16."""
+def conv_rows(conv, x, out_dtype=None, out_gap=0):
+    """Plain 1x1 conv (with bias) on rows, no BatchNorm.  bf16 mode computes in bf16; out_gap: see
+    _LinearBias.forward (bf16 mode only)."""
     if not is_bf16():
         return F.linear(x, _weight2d(conv), conv.bias)
     xr = _rows_bf16(x, pad8(x.shape[1]))
-    y = _LinearBias.apply(xr, conv.weight, conv.bias)
+    y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap)
     return y if out_dtype is None else y.to(out_dtype)
+
+
+class _InterpConcatBF16(torch.autograd.Function):
+    """[skip | interpolated] rows of FeaturePropagation (models/pointnet2_utils.py:191-203) written
+    once, as the bf16 input buffer of the following GEMM: columns [0:D1) = skip features,
+    [pad8(D1) : pad8(D1)+C) = inverse-distance interpolation of feat over the k nearest (from
+    three_nn), everything else zero.  Backward: the interpolation's gradient is reduced per target
+    row over an inverted index (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, skip, feat, d2, idx):
+        B, S, C = feat.shape
+        N, k = d2.shape[1], d2.shape[2]
+        D1 = 0 if skip is None else skip.shape[1]
+        dp = pad8(D1)
+        dev = feat.device
+        out = torch.empty(B * N, dp + C, dtype=torch.bfloat16, device=dev)
+        if skip is not None:
+            out[:, :D1] = skip
+            if dp > D1:
+                out[:, D1:dp] = 0
+        w = torch.empty(B, N, k, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _launch("pcb_interpolate_bf16", 2 * B * N * C, feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S, C,
+                    k, out.data_ptr(), dp + C, dp, w.data_ptr())
+        ctx.save_for_backward(idx, w)
+        ctx.shape = (B, N, S, C, k, D1, dp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, w = ctx.saved_tensors
+        B, N, S, C, k, D1, dp = ctx.shape
+        dev = g.device
+        g = g.contiguous()
+        count = torch.zeros(2, B * S, dtype=torch.int32, device=dev)  # counts | placement cursors
+        entries = torch.empty(B * N * k, dtype=torch.int32, device=dev)
+        gfeat = torch.empty(B, S, C, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            _launch("pcb_interp_csr_count", B * N * k, idx.data_ptr(), B, N, S, k, count[0].data_ptr())
+            offsets = torch.zeros(B * S + 1, dtype=torch.int64, device=dev)
+            offsets[1:] = torch.cumsum(count[0], dim=0)
+            _launch("pcb_interp_csr_fill", B * N * k, idx.data_ptr(), B, N, S, k, offsets.data_ptr(),
+                    count[1].data_ptr(), entries.data_ptr())
+            _launch("pcb_interpolate_bwd_csr_bf16", 2 * B * N * C * k, g.data_ptr(), dp + C, dp, w.data_ptr(),
+                    offsets.data_ptr(), entries.data_ptr(), B, N, S, C, k, gfeat.data_ptr())
+        gskip = g[:, :D1] if (D1 and ctx.needs_input_grad[0]) else None
+        return gskip, gfeat, None, None
+
+
+def interpolate_concat(skip_rows, feat_bsc, d2, idx):
+    """bf16 mode: (rows [B*N, pad8(D1)+C] bf16, perm) with perm = -D1 describing the column layout
+    for conv_bn_act / mlp_rows / conv_rows (0 when there is no gap).  Needs C % 8 == 0."""
+    feat = feat_bsc.to(torch.bfloat16).contiguous()
+    skip = None if skip_rows is None else skip_rows.to(torch.bfloat16)
+    rows = _InterpConcatBF16.apply(skip, feat, d2.contiguous(), idx.contiguous())
+    d1 = 0 if skip is None else skip.shape[1]
+    return rows, (-d1 if d1 % 8 else 0)
 
 
 def bn_act_rows(bn, x, act=ACT_NONE):

@@ -261,3 +261,33 @@ def test_bf16_training_reaches_fp32_miou(rm):
         rm.set_precision("fp32")
     assert miou["fp32"] > 0.5, miou
     assert abs(miou["bf16"] - miou["fp32"]) < 0.05, miou
+
+
+@pytest.mark.parametrize("D1,C,k", [(3, 64, 4), (0, 32, 3), (16, 256, 4), (5, 8, 3)])
+def test_interpolate_concat_bf16_forward_backward(rm, D1, C, k):
+    """bf16 interpolate+concat buffer (gap layout) and its CSR backward against the fp32 operator."""
+    from pointcloud_bridge_amd import ops
+    torch.manual_seed(D1 + C)
+    B, N, S = 2, 700, 90
+    g = torch.Generator().manual_seed(1)
+    xyz1 = torch.rand(B, N, 3, generator=g).cuda()
+    xyz2 = torch.rand(B, S, 3, generator=g).cuda()
+    feat = torch.randn(B, S, C, generator=g).cuda().to(torch.bfloat16).requires_grad_(True)
+    skip = torch.randn(B * N, D1, generator=g).cuda().to(torch.bfloat16).requires_grad_(True) if D1 else None
+    d2, idx = ops.three_nn(xyz1, xyz2, k)
+    rows, perm = rm.interpolate_concat(skip, feat, d2, idx)
+    dp = (D1 + 7) // 8 * 8
+    assert rows.shape == (B * N, dp + C) and perm == (-D1 if D1 % 8 else 0)
+    ref_feat = feat.detach().float().requires_grad_(True)
+    ref = ops.three_interpolate(ref_feat, d2, idx).view(B * N, C)
+    assert float((rows[:, dp:].float() - ref).abs().max()) < 1e-2 * float(ref.abs().max())
+    if D1:
+        assert torch.equal(rows[:, :D1], skip.detach())
+        assert float(rows[:, D1:dp].abs().max()) == 0.0 if dp > D1 else True
+    gr = torch.randn(rows.shape, device="cuda").to(torch.bfloat16)
+    rows.backward(gr)
+    (ref * gr[:, dp:].float()).sum().backward()
+    d = (feat.grad.float() - ref_feat.grad).abs()
+    assert float(d.mean()) < 1e-2 * float(ref_feat.grad.abs().mean())
+    if D1:
+        assert torch.equal(skip.grad, gr[:, :D1])
