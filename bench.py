@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train: fwd+loss+bwd+all-reduce+Adam (the headline metric); infer: eval-mode forward only, "
                          "the reference's own published metric (eva_model.py:137-168, model_performance_comparison.csv)")
+    ap.add_argument("--graph", action="store_true",
+                    help="train mode: replay forward+backward as one captured hipGraph instead of launching every "
+                         "kernel from the host (measured equal on MI355X: the step is GPU-bound, so off by default)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="pointwise-MLP arithmetic: bf16 activations (BASELINE config 2) or the fp32 parity mode")
     args = ap.parse_args()
@@ -128,7 +131,8 @@ def main():
     if args.sync_bn and world > 1:
         model = parallel.sync_batchnorm(model)
     parallel.broadcast_parameters(model)
-    bucket = parallel.FlatGradAllReduce(model.parameters())
+    use_graph = args.mode == "train" and args.graph and args.precision == "bf16"
+    bucket = parallel.FlatGradAllReduce(model.parameters(), keep_grad_tensors=use_graph)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4,
                            fused=True)  # train_MulSca_PN2.py:125
     xyz, colors, labels = synthetic_batch(B, N, 1000 + rank, device)
@@ -154,6 +158,74 @@ def main():
         model.eval()
     step = train_step if args.mode == "train" else infer_step
 
+    if use_graph:
+        # Forward + loss + backward (+ the next batch's sampling pyramid on a side stream) replayed
+        # as ONE hipGraph: ~700 kernel launches per step stop costing host time.  The CPU-generator
+        # draws for FPS stay on the host (StaticSampling.draw), the gradient all-reduce (RCCL) and the
+        # fused Adam step stay outside the graph.
+        from pointcloud_bridge_amd.models import pointnet2_utils as pu
+        static = None
+        if hasattr(model, "prefetch"):
+            static = pu.StaticSampling(xyz, [model.sa1.npoint, model.sa2.npoint, model.sa3.npoint])
+            pu.set_static_sampling(static)
+            static.draw()
+            static.compute(xyz)
+        side = torch.cuda.Stream()
+        loss_buf = torch.zeros((), device=device)
+
+        def fwd_bwd():
+            loss = loss_fn(model(xyz, colors), labels, cdim)
+            if static is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    static.compute(xyz)          # pyramid of the next batch, beside the backward pass
+            loss.backward()
+            if static is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            loss_buf.copy_(loss.detach())
+
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(3):                   # eager warm-up on the capture stream
+                bucket.zero()
+                if static is not None:
+                    static.draw()
+                fwd_bwd()
+                bucket.reduce()
+                opt.step()
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        bucket.zero()
+        graph = torch.cuda.CUDAGraph()
+        if static is not None:
+            static.draw()
+        with torch.cuda.graph(graph):
+            fwd_bwd()
+
+        grads = [p.grad for p in model.parameters() if p.grad is not None]  # the graph's fixed tensors
+
+        def graph_step():
+            if static is not None:
+                static.draw()
+            graph.replay()
+            bucket.reduce()
+            opt.step()
+            return loss_buf
+
+        def eager_step():
+            """The same step launched kernel by kernel (HIP events around the roofline kernel need
+            real launches); gradients accumulate into the graph's tensors, zeroed first."""
+            if static is not None:
+                static.draw()
+            torch._foreach_zero_(grads)
+            fwd_bwd()
+            bucket.reduce()
+            opt.step()
+            return loss_buf
+
+        step = graph_step
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
@@ -166,8 +238,10 @@ def main():
     ops.kernel_timer_start(ROOFLINE_KERNEL)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ops.kernel_timer_enable(i % 5 == 0)  # HIP events around the roofline kernel on every 5th step
-        loss = step()
+        # HIP events around the roofline kernel on every 5th step (launched eagerly in graph mode)
+        sampled = i % 5 == 0 and not os.environ.get("PCB_BENCH_NO_ROOFLINE")
+        ops.kernel_timer_enable(sampled)
+        loss = (eager_step if (use_graph and sampled) else step)()
     fence()
     dt = time.perf_counter() - t0
     launches, kernel_ms, units = ops.kernel_timer_stop()

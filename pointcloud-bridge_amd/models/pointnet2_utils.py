@@ -84,8 +84,72 @@ def prefetch_sampling(xyz, npoints):
             cur = new_xyz
 
 
+class StaticSampling:
+    """The sampling pyramid in persistent device buffers, for steps replayed from a hipGraph.
+
+    A captured step cannot draw from the CPU generator or allocate.  So the start indices live in
+    static device tensors that `draw()` refreshes on the host before every replay (same
+    torch.randint calls, same order as farthest_point_sample), and `compute(xyz)` enqueues the FPS
+    pyramid of the NEXT batch into static (idx, new_xyz) buffers -- inside the captured step, on a
+    side stream next to the backward pass.  SetAbstraction / MultiScaleSetAbstraction read the
+    buffers (see _sample) while a pipeline is installed with set_static_sampling()."""
+
+    def __init__(self, xyz, npoints):
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        self.levels = []
+        n_in = N
+        for s in npoints:
+            self.levels.append({
+                "n_in": n_in, "npoint": int(s),
+                "pinned": torch.zeros(B, dtype=torch.long).pin_memory(),
+                "start": torch.zeros(B, dtype=torch.long, device=dev),
+                "idx": torch.zeros(B, int(s), dtype=torch.long, device=dev),
+                "new_xyz": torch.zeros(B, int(s), 3, dtype=torch.float32, device=dev)})
+            n_in = int(s)
+
+    def draw(self):
+        """Host side, outside any capture: one torch.randint per level from the CPU generator
+        (reference :69), staged through pinned memory into the static start buffers."""
+        for lv in self.levels:
+            B = lv["start"].shape[0]
+            lv["pinned"].copy_(torch.randint(0, lv["n_in"], (B,), dtype=torch.long))
+            lv["start"].copy_(lv["pinned"], non_blocking=True)
+
+    def compute(self, xyz):
+        """Enqueue the whole pyramid for `xyz` on the current stream (capturable)."""
+        cur = xyz
+        for lv in self.levels:
+            ops.furthest_point_sample_into(cur, lv["start"], lv["idx"])
+            ops.gather_rows_into(cur, lv["idx"], lv["new_xyz"])
+            cur = lv["new_xyz"]
+
+    def lookup(self, xyz, npoint):
+        prev = None
+        for lv in self.levels:
+            if lv["npoint"] == int(npoint) and (prev is None or xyz.data_ptr() == prev["new_xyz"].data_ptr()):
+                if xyz.shape[1] == lv["n_in"]:
+                    return lv["idx"], lv["new_xyz"]
+            prev = lv
+        return None
+
+
+_static = None
+
+
+def set_static_sampling(pipeline):
+    """Install (or remove, with None) a StaticSampling pipeline for subsequent forward passes."""
+    global _static
+    _static = pipeline
+
+
 def _sample(xyz, npoint):
-    """(fps_idx, new_xyz) for this level: the prefetched pair if there is one, else computed now."""
+    """(fps_idx, new_xyz) for this level: static buffers of a captured step, else the prefetched
+    pair if there is one, else computed now."""
+    if _static is not None:
+        hit = _static.lookup(xyz, npoint)
+        if hit is not None:
+            return hit
     hit = _prefetched.pop(_key(xyz, npoint), None)
     if hit is None:
         idx = farthest_point_sample(xyz, npoint)

@@ -123,6 +123,24 @@ def furthest_point_sample(xyz, npoint, start_idx):
     return out
 
 
+def furthest_point_sample_into(xyz, start_idx, out_idx):
+    """pcb_fps writing into a caller-owned [B,S] int64 tensor (static buffers of captured steps)."""
+    B, N, _ = xyz.shape
+    with torch.cuda.device(xyz.device):
+        _launch("pcb_fps", B * N * out_idx.shape[1], xyz.data_ptr(), B, N, out_idx.shape[1], start_idx.data_ptr(),
+                out_idx.data_ptr())
+    return out_idx
+
+
+def gather_rows_into(points, idx, out):
+    """pcb_gather_rows (no autograd) writing into a caller-owned [B,M,C] fp32 tensor."""
+    B, N, C = points.shape
+    M = idx.shape[1]
+    with torch.cuda.device(points.device):
+        _launch("pcb_gather_rows", B * M * C, points.data_ptr(), idx.data_ptr(), B, N, C, M, out.data_ptr())
+    return out
+
+
 def _r2(radius):
     # python double square, one rounding to fp32: what ATen does with the scalar in
     # `sqrdists > radius ** 2` (pointnet2_utils.py:105)

@@ -52,9 +52,13 @@ class FlatGradAllReduce:
     reduce() packs them into ONE flat fp32 buffer with one concatenation, all-reduces it once and
     hands each parameter a view of the averaged buffer.  With a single rank both are no-ops."""
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, keep_grad_tensors=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        # keep_grad_tensors: the averaged values are copied back into the existing .grad tensors
+        # instead of re-pointing .grad at the flat buffer (needed when a captured hipGraph writes
+        # the gradients into fixed tensors on every replay)
+        self.keep = keep_grad_tensors
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.flat = None
         for p in self.params:
@@ -74,10 +78,16 @@ class FlatGradAllReduce:
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(self.world)
         off = 0
+        views = []
         for p in live:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            views.append(self.flat[off:off + n].view_as(p))
             off += n
+        if self.keep:
+            torch._foreach_copy_([p.grad for p in live], views)
+        else:
+            for p, v in zip(live, views):
+                p.grad = v
 
 
 def broadcast_parameters(module, src=0, group=None):
