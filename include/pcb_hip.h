@@ -179,7 +179,7 @@ int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream
 /*
  * BatchNorm bookkeeping of one layer: scale = gamma*invstd, shift = beta - mean*scale.
  * `sums` is [nparts][2][C]: nparts partial (sum, sum of squares) slabs, added here in slab order
- * (nparts = 1 after pcb_colstats_bf16, pcb_gemm_nt_partials(R,N) after pcb_gemm_nt_bf16).
+ * (nparts = 1 after pcb_colstats_bf16, pcb_gemm_nt_partials(pro,R,N) after pcb_gemm_nt_bf16).
  * training != 0: batch statistics from sums/rows, running_mean/var updated with `momentum`
  * (unbiased variance), `bias` (the conv bias the GEMM leaves out because it cancels inside a
  * train-mode BatchNorm) added to the mean that enters running_mean.  training == 0: running
@@ -246,7 +246,7 @@ int pcb_group_rows_bf16_bwd(const void *grad_rows, const int64_t *idx, int B, in
  */
 
 /* out[R,N] (bf16) = A'[R,K] . w[N,K]^T, fp32 accumulation.  If sums != NULL it is a
- * [pcb_gemm_nt_partials(R,N)][2][N] fp32 buffer: every workgroup stores the column sums / sums of
+ * [pcb_gemm_nt_partials(pro,R,N)][2][N] fp32 buffer: every workgroup stores the column sums / sums of
  * squares of the rounded outputs it produced into its own slab (no atomics; pcb_bn_finalize adds
  * the slabs).  N % 8 == 0, K % 8 == 0. */
 int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale, const float *shift,
@@ -255,7 +255,7 @@ int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale
                      void *stream);
 
 /* Number of per-workgroup statistics slabs pcb_gemm_nt_bf16 writes for these sizes. */
-int pcb_gemm_nt_partials(long R, int N);
+int pcb_gemm_nt_partials(int pro, long R, int N);
 
 /* dW[M,N] (fp32, overwritten) = A'[R,M]^T . B'[R,N].
  * A' = dz [R,M] itself (apro 0) or dy (apro 2 or 3, as above, built from dz|dout+argmax and y [R,M]);
@@ -271,10 +271,22 @@ int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const float *scale
 /* Number of fp32 elements pcb_gemm_tn_bf16 needs in `workspace` for these sizes. */
 long pcb_gemm_tn_workspace(long R, int M, int N);
 
-/* p, q of the fused BatchNorm backward from sums = (sum du, sum du*xhat):
- * p = -scale*invstd*s2/rows, q = -scale*s1/rows - p*mean; zeros when use_batch_stats == 0. */
-int pcb_bn_bwd_finalize(const float *sums, long rows, int C, const float *scale, const float *mean,
-                        const float *invstd, int use_batch_stats, float *p, float *q, void *stream);
+/* p, q of the fused BatchNorm backward from sums = [nparts][2][C] partial slabs of
+ * (sum du, sum du*xhat): p = -scale*invstd*s2/rows, q = -scale*s1/rows - p*mean; zeros when
+ * use_batch_stats == 0.  total [2][C] (optional) receives the slab totals (= dbeta, dgamma). */
+int pcb_bn_bwd_finalize(const float *sums, int nparts, long rows, int C, const float *scale,
+                        const float *mean, const float *invstd, int use_batch_stats, float *p, float *q,
+                        float *total, void *stream);
+
+/* pcb_gemm_nt_bf16 (pro 2 or 3, N <= 128) whose epilogue also accumulates the BatchNorm-backward
+ * sums of the layer BELOW: the produced tile is that layer's dz; with its y (red_y [R,N] bf16) and
+ * constants, (sum du, sum du*xhat) go to red_sums = [pcb_gemm_nt_partials(pro,R,N)][2][N] slabs.
+ * Saves the separate pcb_bn_act_bwd_reduce_bf16 pass over (dz, y). */
+int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, const float *scale, const float *shift,
+                         const float *p, const float *q, const float *dout, const unsigned char *argmax,
+                         int ns, int act, const void *w, long R, int N, int K, void *out, const void *red_y,
+                         const float *red_scale, const float *red_shift, const float *red_mean,
+                         const float *red_invstd, int red_act, float *red_sums, void *stream);
 
 /* Backward sums only (no dy written): sums += (sum du, sum du*xhat) for a dense dz ... */
 int pcb_bn_act_bwd_reduce_bf16(const void *dz, const void *y, const float *scale, const float *shift,

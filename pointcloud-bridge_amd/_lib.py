@@ -30,7 +30,7 @@ SIGNATURES = {
     "pcb_edge_features_bwd": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_colstats_bf16": [_p, _l, _i, _p, _p],
     "pcb_bn_finalize": [_p, _i, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p],
-    "pcb_gemm_nt_partials": [_l, _i],
+    "pcb_gemm_nt_partials": [_i, _l, _i],
     "pcb_bn_act_bf16": [_p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_max_bf16": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
     "pcb_bn_act_bwd_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
@@ -44,7 +44,8 @@ SIGNATURES = {
     "pcb_gemm_nt_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p],
     "pcb_gemm_tn_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _p],
     "pcb_gemm_tn_workspace": [_l, _i, _i],
-    "pcb_bn_bwd_finalize": [_p, _l, _i, _p, _p, _p, _i, _p, _p, _p],
+    "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p],
+    "pcb_gemm_nt_red_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "pcb_bn_act_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
 }

@@ -53,14 +53,11 @@ __device__ __forceinline__ uint4 pack8(const float *f)
     v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
     return v;
 }
-__device__ __forceinline__ float act_fwd(float u, int act)
-{
-    return act == 1 ? fmaxf(u, 0.0f) : (act == 2 ? (u > 0.0f ? u : 0.2f * u) : u);
-}
-__device__ __forceinline__ float act_grad(float u, int act)
-{
-    return act == 1 ? (u > 0.0f ? 1.0f : 0.0f) : (act == 2 ? (u > 0.0f ? 1.0f : 0.2f) : 1.0f);
-}
+// Activations as one select on a per-launch slope (0 ReLU, 0.2 LeakyReLU, 1 none): testing the
+// activation code per element would put scalar branches into the innermost prologue loops.
+__device__ __forceinline__ float act_slope(int act) { return act == 1 ? 0.0f : (act == 2 ? 0.2f : 1.0f); }
+__device__ __forceinline__ float act_fwd(float u, float slope) { return u > 0.0f ? u : fmaf(slope, u, 0.0f); }
+__device__ __forceinline__ float act_grad(float u, float slope) { return u > 0.0f ? 1.0f : slope; }
 
 // ---- operand prologues ------------------------------------------------------------------------
 enum { PRO_PLAIN = 0, PRO_BNACT = 1, PRO_DY = 2, PRO_DY_POOL = 3 };
@@ -98,16 +95,22 @@ struct Consts {
     __device__ __forceinline__ void load(const Operand &o, int c, int cols)
     {
         if (PRO == PRO_PLAIN) return;
-        const bool ok = c < cols;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            scale[i] = ok ? o.scale[c + i] : 0.0f;
-            shift[i] = ok ? o.shift[c + i] : 0.0f;
-            if (PRO >= PRO_DY) {
-                p[i] = ok ? o.p[c + i] : 0.0f;
-                q[i] = ok ? o.q[c + i] : 0.0f;
-            }
+        // unconditional 16-byte loads from a clamped chunk (cols % 8 == 0, so chunk 0 always exists);
+        // chunks past the matrix are zeroed by Raw::finish, whatever constants they meet
+        const int cs = c < cols ? c : 0;
+        load8(o.scale + cs, scale);
+        load8(o.shift + cs, shift);
+        if (PRO >= PRO_DY) {
+            load8(o.p + cs, p);
+            load8(o.q + cs, q);
         }
+    }
+    static __device__ __forceinline__ void load8(const float *src, float *dst)
+    {
+        const float4 a = *reinterpret_cast<const float4 *>(src);
+        const float4 b = *reinterpret_cast<const float4 *>(src + 4);
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+        dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
     }
 };
 
@@ -136,7 +139,7 @@ struct Raw {
             dptr = o.dout + g * cols + cs;
         }
     }
-    __device__ __forceinline__ uint4 finish(const Consts<PRO> &k, int act) const
+    __device__ __forceinline__ uint4 finish(const Consts<PRO> &k, float slope) const
     {
         const uint32_t keep = live ? 0xffffffffu : 0u;
         if (PRO == PRO_PLAIN) return make_uint4(v0.x & keep, v0.y & keep, v0.z & keep, v0.w & keep);
@@ -144,7 +147,7 @@ struct Raw {
         if (PRO == PRO_BNACT) {
             unpack8(v0, f);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] = act_fwd(fmaf(f[i], k.scale[i], k.shift[i]), act);
+            for (int i = 0; i < 8; ++i) f[i] = act_fwd(fmaf(f[i], k.scale[i], k.shift[i]), slope);
             const uint4 r = pack8(f);
             return make_uint4(r.x & keep, r.y & keep, r.z & keep, r.w & keep);
         }
@@ -161,7 +164,7 @@ struct Raw {
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float du = f[i] * act_grad(fmaf(y[i], k.scale[i], k.shift[i]), act);
+            const float du = f[i] * act_grad(fmaf(y[i], k.scale[i], k.shift[i]), slope);
             f[i] = fmaf(k.scale[i], du, fmaf(k.p[i], y[i], k.q[i]));
         }
         const uint4 r = pack8(f);
@@ -175,17 +178,31 @@ constexpr int NT_LD = NT_BK + 8;  // LDS row stride in bf16 (144 B): conflict-fr
 constexpr int NT_OUT_LD = NT_BN + 8;  // row stride of the per-wave output staging block (272 B)
 static_assert(4 * 32 * NT_OUT_LD <= (NT_BM + NT_BN) * NT_LD, "output staging must fit the stage buffers");
 
-template <int PRO, int STATS>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
+// Optional epilogue of an input-gradient GEMM: the tile it has just produced is dz of the layer
+// below; with that layer's y and BatchNorm constants the sums s1 = sum du, s2 = sum du*xhat of ITS
+// BatchNorm backward are accumulated here, which saves the separate reduction pass over (dz, y).
+struct RedArgs {
+    const u16 *y;                              // [R, N] bf16: pre-BatchNorm output of the layer below
+    const float *scale, *shift, *mean, *invstd;  // its per-column constants
+    int act;
+};
+
+template <int PRO, int STATS, int RED>
+__global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
                                                        int N, int K, u16 *__restrict__ out,
-                                                       float *__restrict__ sums)
+                                                       float *__restrict__ sums, RedArgs red_arg)
 {
     const Operand A = local_copy(A_arg);
+    const float a_slope = act_slope(A.act), red_slope = act_slope(red_arg.act);
+    RedArgs red;
+    red.y = red_arg.y; red.scale = red_arg.scale; red.shift = red_arg.shift;
+    red.mean = red_arg.mean; red.invstd = red_arg.invstd; red.act = red_arg.act;
     // one LDS array: [A stage | B stage] in the main loop, per-wave output staging in the epilogue
     __shared__ __attribute__((aligned(16))) u16 smem[(NT_BM + NT_BN) * NT_LD];
     u16 *const As = smem;
     u16 *const Bs = smem + NT_BM * NT_LD;
     __shared__ float ssum[4 * 2 * NT_BN];
+    __shared__ __attribute__((aligned(16))) float rconst[RED ? 4 * NT_BN : 4];  // RED: scale|shift|mean|invstd of this column tile
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -203,13 +220,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
     if (tile >= tiles_m) return;
 
     f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
     // statistics: each lane owns one output column per 32-wide tile for the whole kernel, so the
     // column sums live in 8 registers and meet the other lanes/waves only once, at the very end
     float st_s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, st_q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (RED) {
+        for (int i = t; i < 4 * 2 * NT_BN; i += 256) ssum[i] = 0.0f;  // per-wave (s1, s2) slabs
+        if (t < NT_BN) {
+            const bool ok = n0 + t < N;
+            rconst[0 * NT_BN + t] = ok ? red.scale[n0 + t] : 0.0f;
+            rconst[1 * NT_BN + t] = ok ? red.shift[n0 + t] : 0.0f;
+            rconst[2 * NT_BN + t] = ok ? red.mean[n0 + t] : 0.0f;
+            rconst[3 * NT_BN + t] = ok ? red.invstd[n0 + t] : 0.0f;
+        }
+    }
 
     Raw<PRO> ra[4];
     Consts<PRO> ka;
@@ -230,13 +253,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
     };
     fetch(tile, 0);
     for (; tile < tiles_m; tile += gridDim.x) {
+        // zeroed here, not in the epilogue: the accumulators are then dead during the read-back,
+        // which leaves their registers to the RED epilogue's operands
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
         for (int k0 = 0; k0 < K; k0 += NT_BK) {
             // per-column constants of this stage's chunk: L1/L2-resident, fetched here rather than
             // with the prefetch so that they are not live across the MFMA section
             ka.load(A, k0 + chunk * 8, K);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<uint4 *>(&As[(rrow + 32 * i) * NT_LD + chunk * 8]) = ra[i].finish(ka, A.act);
+                *reinterpret_cast<uint4 *>(&As[(rrow + 32 * i) * NT_LD + chunk * 8]) = ra[i].finish(ka, a_slope);
                 *reinterpret_cast<uint4 *>(&Bs[(rrow + 32 * i) * NT_LD + chunk * 8]) =
                     make_uint4(rb[i].x & keepb[i], rb[i].y & keepb[i], rb[i].z & keepb[i], rb[i].w & keepb[i]);
             }
@@ -266,6 +295,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
         // two-byte ones.
         const long m0 = tile * NT_BM;
         u16 *const stage = smem + wave * (32 * NT_OUT_LD);
+        // RED: the y rows of this tile are requested BEFORE the tile is stored.  (A load issued after
+        // a store has to wait for the store's acknowledgement too -- the memory counter is shared --
+        // and eight such round trips per tile cost more than the GEMM.)  Unconditional, from clamped
+        // addresses: rows/columns outside the matrix meet dz = 0 below and contribute nothing.
+        uint4 yraw[RED ? 8 : 1];
+        if (RED) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int ch = v * 64 + lane;
+                const long r = m0 + wave * 32 + (ch >> 4);
+                const int n = n0 + (ch & 15) * 8;
+                yraw[v] = *reinterpret_cast<const uint4 *>(red.y + (r < R ? r : R - 1) * N + (n < N ? n : 0));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float sv = 0.0f, sq = 0.0f;
@@ -279,7 +322,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
                     sv += v;
                     sq = fmaf(v, v, sq);
                 }
-                acc[j][i] = 0.0f;
             }
             if (STATS) {
                 st_s[j] += sv;
@@ -289,24 +331,64 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand A_arg, const u16 *
         // same wave wrote and reads its slice: a wave-level LDS fence is enough
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        // every lane handles the same 8 columns in all of its 8 chunks: cc = (lane & 15) * 8
+        float rs1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rs2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             const int ch = v * 64 + lane;     // 512 chunks of 8 columns: 32 rows x 16 chunks
             const int rr = ch >> 4, cc = (ch & 15) * 8;
             const long r = m0 + wave * 32 + rr;
             const int n = n0 + cc;
-            if (r < R && n < N)
-                *reinterpret_cast<uint4 *>(out + r * N + n) =
-                    *reinterpret_cast<const uint4 *>(&stage[rr * NT_OUT_LD + cc]);
+            const uint4 o = *reinterpret_cast<const uint4 *>(&stage[rr * NT_OUT_LD + cc]);
+            if (r < R && n < N) *reinterpret_cast<uint4 *>(out + r * N + n) = o;
+            if (RED) {
+                float dz[8], yv[8];
+                unpack8(o, dz);
+                unpack8(yraw[v], yv);
+                const int c8 = (lane & 15) * 8;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(&rconst[0 * NT_BN + c8 + 4 * h]);
+                    const float4 sh = *reinterpret_cast<const float4 *>(&rconst[1 * NT_BN + c8 + 4 * h]);
+                    const float4 mu = *reinterpret_cast<const float4 *>(&rconst[2 * NT_BN + c8 + 4 * h]);
+                    const float4 is = *reinterpret_cast<const float4 *>(&rconst[3 * NT_BN + c8 + 4 * h]);
+                    const float rsc[4] = {sc.x, sc.y, sc.z, sc.w}, rsh[4] = {sh.x, sh.y, sh.z, sh.w};
+                    const float rmu[4] = {mu.x, mu.y, mu.z, mu.w}, ris[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = 4 * h + i;
+                        const float du = dz[e] * act_grad(fmaf(yv[e], rsc[i], rsh[i]), red_slope);
+                        rs1[e] += du;
+                        rs2[e] = fmaf(du, (yv[e] - rmu[i]) * ris[i], rs2[e]);
+                    }
+                }
+            }
+        }
+        if (RED) {
+            // lanes l, l+16, l+32, l+48 share their columns; lanes 0..15 add into the wave's slab
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                rs1[i] += __shfl_xor(rs1[i], 16);
+                rs1[i] += __shfl_xor(rs1[i], 32);
+                rs2[i] += __shfl_xor(rs2[i], 16);
+                rs2[i] += __shfl_xor(rs2[i], 32);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    ssum[(wave * 2 + 0) * NT_BN + lane * 8 + i] += rs1[i];
+                    ssum[(wave * 2 + 1) * NT_BN + lane * 8 + i] += rs2[i];
+                }
+            }
         }
         __syncthreads();  // the next stage's LDS writes must not overtake another wave's read-back
     }
-    if (STATS) {
+    if (STATS || RED) {
         // lanes l and l+32 hold the same column (different rows); then the 4 waves meet in LDS; the
-        // workgroup's totals go to ITS slot of the partials buffer (no atomics: pcb_bn_finalize sums
-        // the slots in a fixed order)
+        // workgroup's totals go to ITS slot of the partials buffer (no atomics: pcb_bn_finalize /
+        // pcb_bn_bwd_finalize sum the slots in a fixed order)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < (STATS ? 4 : 0); ++j) {
             const float s2 = st_s[j] + __shfl_xor(st_s[j], 32);
             const float q2 = st_q[j] + __shfl_xor(st_q[j], 32);
             if (lane < 32) {
@@ -338,10 +420,11 @@ constexpr int AR_BLD = AR_BK + 8;
 constexpr int AR_OLD = 64 + 8;  // per-wave output staging: 32 rows x 64 columns
 
 template <int PRO, int KCH>  // KCH = K/8 chunks per row held in LDS: 16 (K <= 128) or 32 (K <= 256)
-__global__ __launch_bounds__(256) void gemm_nt_ares_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
+__global__ __launch_bounds__(256, 2) void gemm_nt_ares_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
                                                             int N, int K, u16 *__restrict__ out)
 {
     const Operand A = local_copy(A_arg);
+    const float a_slope = act_slope(A.act);
     constexpr int ALD = KCH * 8 + 8;      // A row stride in bf16: rows 16 B apart in bank space
     constexpr int RPT = 256 / KCH;        // rows covered by one pass of the 256 threads
     __shared__ __attribute__((aligned(16))) u16 As[AR_BM * ALD];
@@ -379,7 +462,7 @@ __global__ __launch_bounds__(256) void gemm_nt_ares_kernel(Operand A_arg, const 
             for (int i = 0; i < AR_BM / RPT; ++i) ra[i].load(A, m0 + t / KCH + RPT * i, kc, R, K);
 #pragma unroll
             for (int i = 0; i < AR_BM / RPT; ++i)
-                *reinterpret_cast<uint4 *>(&As[(t / KCH + RPT * i) * ALD + kc]) = ra[i].finish(ka, A.act);
+                *reinterpret_cast<uint4 *>(&As[(t / KCH + RPT * i) * ALD + kc]) = ra[i].finish(ka, a_slope);
         }
         fetch_b(0, 0);
         __syncthreads();
@@ -438,11 +521,12 @@ constexpr int TN_BM = 128, TN_BN = 128, TN_RS = 32;  // RS rows of the reduction
 constexpr int TN_LD = 128 + 32;                       // row stride 320 B: conflict-free tr reads
 
 template <int APRO, int BPRO>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(Operand A_arg, Operand B_arg, long R, int M, int N,
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand B_arg, long R, int M, int N,
                                                        long rows_per_split, float *__restrict__ part)
 {
     const Operand A = local_copy(A_arg);
     const Operand B = local_copy(B_arg);
+    const float a_slope = act_slope(A.act), b_slope = act_slope(B.act);
     __shared__ __attribute__((aligned(16))) u16 As[TN_RS * TN_LD];
     __shared__ __attribute__((aligned(16))) u16 Bs[TN_RS * TN_LD];
 
@@ -491,8 +575,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(Operand A_arg, Operand B_a
     for (long r0 = r_begin; r0 < r_end; r0 += TN_RS) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<uint4 *>(&As[(rrow + 16 * i) * TN_LD + chunk * 8]) = ra[i].finish(ka, A.act);
-            *reinterpret_cast<uint4 *>(&Bs[(rrow + 16 * i) * TN_LD + chunk * 8]) = rb[i].finish(kb, B.act);
+            *reinterpret_cast<uint4 *>(&As[(rrow + 16 * i) * TN_LD + chunk * 8]) = ra[i].finish(ka, a_slope);
+            *reinterpret_cast<uint4 *>(&Bs[(rrow + 16 * i) * TN_LD + chunk * 8]) = rb[i].finish(kb, b_slope);
         }
         __syncthreads();
         if (r0 + TN_RS < r_end) fetch(r0 + TN_RS);
@@ -559,39 +643,79 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restr
     }
 }
 
-// p, q of the fused BatchNorm backward and the affine-parameter gradients of one layer.
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ sums, long rows, int C,
-                                       const float *__restrict__ scale, const float *__restrict__ mean,
-                                       const float *__restrict__ invstd, int use_batch_stats,
-                                       float *__restrict__ p, float *__restrict__ q)
+// p, q of the fused BatchNorm backward of one layer from sums = [nparts][2][C] partial slabs of
+// (sum du, sum du*xhat); the slab totals are also written to `total` [2][C] (= dbeta, dgamma).
+// Block = 32 channels x 32 slab-lanes.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ sums, int nparts,
+                                                                long rows, int C, const float *__restrict__ scale,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd,
+                                                                int use_batch_stats, float *__restrict__ p,
+                                                                float *__restrict__ q, float *__restrict__ total)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[2][32][32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s1 = 0.0f, s2 = 0.0f;
+    if (c < C) {
+        for (int k = pl; k < nparts; k += 32) {
+            s1 += sums[((long)k * 2 + 0) * C + c];
+            s2 += sums[((long)k * 2 + 1) * C + c];
+        }
+    }
+    red[0][pl][cl] = s1;
+    red[1][pl][cl] = s2;
+    __syncthreads();
+    if (pl != 0 || c >= C) return;
+    s1 = 0.0f;
+    s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        s1 += red[0][k][cl];
+        s2 += red[1][k][cl];
+    }
+    if (total) {
+        total[c] = s1;
+        total[C + c] = s2;
+    }
     if (!use_batch_stats) {
         p[c] = 0.0f;
         q[c] = 0.0f;
         return;
     }
     const float invR = 1.0f / (float)rows;
-    const float a = sums[c] * invR;       // mean of du
-    const float b = sums[C + c] * invR;   // mean of du * xhat
+    const float a = s1 * invR;       // mean of du
+    const float b = s2 * invR;       // mean of du * xhat
     const float sb = scale[c] * b * invstd[c];
     p[c] = -sb;
     q[c] = fmaf(sb, mean[c], -scale[c] * a);
 }
 
-template <int PRO>
-void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, float *sums, hipStream_t st)
+// Workgroups along x of a gemm_nt launch (= slabs of its partials buffer): persistent over row
+// tiles, as many as are resident at once -- 3 per CU for the forward prologues, 2 for the
+// register-heavier backward ones (see the launch bounds of gemm_nt_kernel).
+long nt_grid_x(int pro, long R, int N)
 {
-    long tiles = (R + NT_BM - 1) / NT_BM;
+    const long tiles = (R + NT_BM - 1) / NT_BM;
+    const long ny = (N + NT_BN - 1) / NT_BN;
+    const long chip = pro <= PRO_BNACT ? 768 : 512;
+    const long resident = chip / ny > 0 ? chip / ny : 1;
+    return tiles < resident ? tiles : resident;
+}
+
+template <int PRO>
+void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, float *sums, hipStream_t st,
+               const RedArgs *red = nullptr)
+{
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
-    static const long kResident = getenv("PCB_NT_RESIDENT") ? atol(getenv("PCB_NT_RESIDENT")) : 512;
-    const long resident = kResident / ny > 0 ? kResident / ny : 1;  // ~2 workgroups per CU in total, persistent over row tiles
-    const dim3 grid((unsigned)(tiles < resident ? tiles : resident), ny);
-    if (sums)
-        hipLaunchKernelGGL((gemm_nt_kernel<PRO, 1>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums);
+    const dim3 grid((unsigned)nt_grid_x(PRO, R, N), ny);
+    RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (red && PRO >= PRO_DY)
+        hipLaunchKernelGGL((gemm_nt_kernel<PRO, 0, (PRO >= PRO_DY)>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums, *red);
+    else if (sums)
+        hipLaunchKernelGGL((gemm_nt_kernel<PRO, 1, 0>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums, none);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<PRO, 0>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums);
+        hipLaunchKernelGGL((gemm_nt_kernel<PRO, 0, 0>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums, none);
 }
 
 // Row splits of the weight-gradient GEMM: enough workgroups to fill the chip (~1024), at least 8
@@ -717,14 +841,10 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
     return pcb_check_launch();
 }
 
-extern "C" int pcb_gemm_nt_partials(long R, int N)
+extern "C" int pcb_gemm_nt_partials(int pro, long R, int N)
 {
-    if (R <= 0 || N <= 0) return 0;
-    const long tiles = (R + NT_BM - 1) / NT_BM;
-    const long ny = (N + NT_BN - 1) / NT_BN;
-    static const long kResident = getenv("PCB_NT_RESIDENT") ? atol(getenv("PCB_NT_RESIDENT")) : 512;
-    const long resident = kResident / ny > 0 ? kResident / ny : 1;
-    return (int)(tiles < resident ? tiles : resident);
+    if (R <= 0 || N <= 0 || pro < 0 || pro > 3) return 0;
+    return (int)nt_grid_x(pro, R, N);
 }
 
 extern "C" long pcb_gemm_tn_workspace(long R, int M, int N)
@@ -734,12 +854,39 @@ extern "C" long pcb_gemm_tn_workspace(long R, int M, int N)
     return tn_splits(R, M, N, &rps) * (long)M * N;
 }
 
-extern "C" int pcb_bn_bwd_finalize(const float *sums, long rows, int C, const float *scale,
+extern "C" int pcb_bn_bwd_finalize(const float *sums, int nparts, long rows, int C, const float *scale,
                                    const float *mean, const float *invstd, int use_batch_stats, float *p,
-                                   float *q, void *stream)
+                                   float *q, float *total, void *stream)
 {
-    if (!sums || !scale || !mean || !invstd || !p || !q || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
-                       rows, C, scale, mean, invstd, use_batch_stats, p, q);
+    if (!sums || nparts < 1 || !scale || !mean || !invstd || !p || !q || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums,
+                       nparts, rows, C, scale, mean, invstd, use_batch_stats, p, q, total);
+    return pcb_check_launch();
+}
+
+// pcb_gemm_nt_bf16 for an input-gradient GEMM (pro 2 or 3) that ALSO accumulates the BatchNorm
+// backward sums of the layer below (see RedArgs): red_sums is [pcb_gemm_nt_partials(pro,R,N)][2][N].
+// Falls back to the plain kernel + no sums (returns 1) when the wide-output variant applies.
+extern "C" int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, const float *scale,
+                                    const float *shift, const float *p, const float *q, const float *dout,
+                                    const unsigned char *argmax, int ns, int act, const void *w, long R, int N,
+                                    int K, void *out, const void *red_y, const float *red_scale,
+                                    const float *red_shift, const float *red_mean, const float *red_invstd,
+                                    int red_act, float *red_sums, void *stream)
+{
+    if (!w || !out || R <= 0 || !red_y || !red_scale || !red_shift || !red_mean || !red_invstd || !red_sums)
+        return PCB_ERR_INVALID_ARG;
+    if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
+    if (pro != PRO_DY && pro != PRO_DY_POOL) return PCB_ERR_INVALID_ARG;
+    if (!a1 || !scale || !shift || !p || !q || (pro == PRO_DY && !a0)) return PCB_ERR_INVALID_ARG;
+    if (pro == PRO_DY_POOL && (!dout || !argmax || ns <= 0 || ns > 255)) return PCB_ERR_INVALID_ARG;
+    if (N > NT_BN) return PCB_ERR_UNSUPPORTED;  // one column tile only (the caller checks N <= 128)
+    const Operand A = make_operand(a0, a1, K, scale, shift, p, q, dout, argmax, ns, act);
+    const RedArgs red = {(const u16 *)red_y, red_scale, red_shift, red_mean, red_invstd, red_act};
+    hipStream_t st = (hipStream_t)stream;
+    if (pro == PRO_DY)
+        launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, st, &red);
+    else
+        launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, st, &red);
     return pcb_check_launch();
 }

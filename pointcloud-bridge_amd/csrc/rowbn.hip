@@ -41,14 +41,10 @@ __device__ __forceinline__ uint4 pack8(const float *f)
 }
 
 // activation codes shared with the host: 0 none, 1 ReLU, 2 LeakyReLU(0.2)
-__device__ __forceinline__ float act_fwd(float u, int act)
-{
-    return act == 1 ? fmaxf(u, 0.0f) : (act == 2 ? (u > 0.0f ? u : 0.2f * u) : u);
-}
-__device__ __forceinline__ float act_grad(float u, int act)
-{
-    return act == 1 ? (u > 0.0f ? 1.0f : 0.0f) : (act == 2 ? (u > 0.0f ? 1.0f : 0.2f) : 1.0f);
-}
+// (applied as one select on a per-launch slope: no per-element tests of the activation code)
+inline float slope_of(int act) { return act == 1 ? 0.0f : (act == 2 ? 0.2f : 1.0f); }  // host side
+__device__ __forceinline__ float act_fwd(float u, float slope) { return u > 0.0f ? u : fmaf(slope, u, 0.0f); }
+__device__ __forceinline__ float act_grad(float u, float slope) { return u > 0.0f ? 1.0f : slope; }
 
 constexpr int kThreads = 256;
 
@@ -158,7 +154,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
 __global__ __launch_bounds__(kThreads) void bn_act_kernel(const uint4 *__restrict__ y,
                                                            const float *__restrict__ scale,
                                                            const float *__restrict__ shift, int C,
-                                                           int act, uint4 *__restrict__ z, long nvec)
+                                                           float act, uint4 *__restrict__ z, long nvec)
 {
     const int CT = C >> 3;
     for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < nvec; e += (long)gridDim.x * kThreads) {
@@ -175,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void bn_act_kernel(const uint4 *__restric
 __global__ __launch_bounds__(kThreads) void bn_act_max_kernel(const uint4 *__restrict__ y,
                                                                const float *__restrict__ scale,
                                                                const float *__restrict__ shift,
-                                                               int C, int ns, int act,
+                                                               int C, int ns, float act,
                                                                uint4 *__restrict__ out,
                                                                unsigned char *__restrict__ arg,
                                                                long nvec /* groups * C/8 */)
@@ -219,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void bn_act_max_kernel(const uint4 *__res
 __global__ __launch_bounds__(kThreads) void bn_act_bwd_reduce_kernel(
     const uint4 *__restrict__ dz, const uint4 *__restrict__ y, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
-    long rows, int C, int act, float *__restrict__ sums)
+    long rows, int C, float act, float *__restrict__ sums)
 {
     __shared__ float red[kThreads * 16];
     const int CT = C >> 3;
@@ -267,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void bn_act_bwd_reduce_kernel(
 __global__ __launch_bounds__(kThreads) void bn_act_bwd_apply_kernel(
     const uint4 *__restrict__ dz, const uint4 *__restrict__ y, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
-    const float *__restrict__ sums, long rows, int C, int act, int use_batch_stats,
+    const float *__restrict__ sums, long rows, int C, float act, int use_batch_stats,
     uint4 *__restrict__ dy, long nvec)
 {
     const int CT = C >> 3;
@@ -294,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void bn_act_bwd_apply_kernel(
 __global__ __launch_bounds__(kThreads) void bn_max_bwd_reduce_kernel(
     const float *__restrict__ dout, const unsigned char *__restrict__ arg, const uint4 *__restrict__ y,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
-    const float *__restrict__ invstd, long groups, int C, int ns, int act, float *__restrict__ sums)
+    const float *__restrict__ invstd, long groups, int C, int ns, float act, float *__restrict__ sums)
 {
     __shared__ float red[kThreads * 16];
     const int CT = C >> 3;
@@ -335,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void bn_max_bwd_apply_kernel(
     const float *__restrict__ dout, const unsigned char *__restrict__ arg, const uint4 *__restrict__ y,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ sums, long rows, int C, int ns,
-    int act, int use_batch_stats, uint4 *__restrict__ dy, long nvec /* rows * C/8 */)
+    float act, int use_batch_stats, uint4 *__restrict__ dy, long nvec /* rows * C/8 */)
 {
     const int CT = C >> 3;
     const float invR = 1.0f / (float)rows;
@@ -452,7 +448,7 @@ extern "C" int pcb_bn_act_bf16(const void *y, const float *scale, const float *s
     if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
     const long nvec = rows * (C >> 3);
     hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(nvec)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const uint4 *)y, scale, shift, C, act, (uint4 *)z, nvec);
+                       (const uint4 *)y, scale, shift, C, slope_of(act), (uint4 *)z, nvec);
     return pcb_check_launch();
 }
 
@@ -464,7 +460,7 @@ extern "C" int pcb_bn_act_max_bf16(const void *y, const float *scale, const floa
     if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
     const long nvec = groups * (C >> 3);
     hipLaunchKernelGGL(bn_act_max_kernel, dim3(grid_for(nvec, kThreads, 8192)), dim3(kThreads), 0,
-                       (hipStream_t)stream, (const uint4 *)y, scale, shift, C, ns, act, (uint4 *)out,
+                       (hipStream_t)stream, (const uint4 *)y, scale, shift, C, ns, slope_of(act), (uint4 *)out,
                        argmax, nvec);
     return pcb_check_launch();
 }
@@ -480,10 +476,10 @@ extern "C" int pcb_bn_act_bwd_bf16(const void *dz, const void *y, const float *s
     const int RT = kThreads / (C >> 3);
     // sums [2,C] must be zero on entry; it returns (dbeta, dgamma) = (s1, s2)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, RT * 8, 2048)), dim3(kThreads), 0, st,
-                       (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd, rows, C, act, sums);
+                       (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd, rows, C, slope_of(act), sums);
     const long nvec = rows * (C >> 3);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(kThreads), 0, st,
-                       (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd, sums, rows, C, act,
+                       (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd, sums, rows, C, slope_of(act),
                        use_batch_stats, (uint4 *)dy, nvec);
     return pcb_check_launch();
 }
@@ -500,11 +496,11 @@ extern "C" int pcb_bn_act_max_bwd_bf16(const float *dout, const unsigned char *a
     hipStream_t st = (hipStream_t)stream;
     const int RT = kThreads / (C >> 3);
     hipLaunchKernelGGL(bn_max_bwd_reduce_kernel, dim3(grid_for(groups, RT * 4, 2048)), dim3(kThreads), 0, st,
-                       dout, argmax, (const uint4 *)y, scale, shift, mean, invstd, groups, C, ns, act, sums);
+                       dout, argmax, (const uint4 *)y, scale, shift, mean, invstd, groups, C, ns, slope_of(act), sums);
     const long rows = groups * ns;
     const long nvec = rows * (C >> 3);
     hipLaunchKernelGGL(bn_max_bwd_apply_kernel, dim3(grid_for(nvec)), dim3(kThreads), 0, st, dout, argmax,
-                       (const uint4 *)y, scale, shift, mean, invstd, sums, rows, C, ns, act,
+                       (const uint4 *)y, scale, shift, mean, invstd, sums, rows, C, ns, slope_of(act),
                        use_batch_stats, (uint4 *)dy, nvec);
     return pcb_check_launch();
 }
@@ -541,7 +537,7 @@ extern "C" int pcb_bn_act_bwd_reduce_bf16(const void *dz, const void *y, const f
     const int RT = kThreads / (C >> 3);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, RT * 8, 2048)), dim3(kThreads), 0,
                        (hipStream_t)stream, (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd,
-                       rows, C, act, sums);
+                       rows, C, slope_of(act), sums);
     return pcb_check_launch();
 }
 
@@ -557,6 +553,6 @@ extern "C" int pcb_bn_act_max_bwd_reduce_bf16(const float *dout, const unsigned 
     const int RT = kThreads / (C >> 3);
     hipLaunchKernelGGL(bn_max_bwd_reduce_kernel, dim3(grid_for(groups, RT * 4, 2048)), dim3(kThreads), 0,
                        (hipStream_t)stream, dout, argmax, (const uint4 *)y, scale, shift, mean, invstd, groups,
-                       C, ns, act, sums);
+                       C, ns, slope_of(act), sums);
     return pcb_check_launch();
 }

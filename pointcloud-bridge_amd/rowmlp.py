@@ -264,7 +264,7 @@ class _FusedStack(torch.autograd.Function):
                 y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
                 st = torch.zeros(10, C, dtype=torch.float32, device=dev)  # sums2|scale|shift|mean|invstd|bsums2|p|q
                 prev = stats[-1] if l else None
-                nparts = lib.pcb_gemm_nt_partials(R, C)
+                nparts = lib.pcb_gemm_nt_partials(1 if l else 0, R, C)
                 parts = torch.empty(nparts, 2, C, dtype=torch.float32, device=dev) if training else None
                 _launch("pcb_gemm_nt_bf16", 2 * R * (cur_k + C), 1 if l else 0, cur.data_ptr(), 0,
                         prev[2].data_ptr() if l else 0, prev[3].data_ptr() if l else 0, 0, 0, 0, 0, 0, act,
@@ -311,21 +311,28 @@ class _FusedStack(torch.autograd.Function):
                 dout = g.float().contiguous()
             else:
                 dz = g.to(torch.bfloat16).contiguous()
+            lib = _lib.load()
+            red_parts = {}  # layer -> (partials, nparts) accumulated by the dgrad GEMM of the layer above
             for l in range(L - 1, -1, -1):
                 y, wp, st = ys[l], wps[l], stats[l]
                 C, K = wp.shape
                 training = trainings[l]
                 pooled = pool and l == L - 1
                 scale, shift, mean, invstd, bsums, p, q = st[2], st[3], st[4], st[5], st[6:8], st[8], st[9]
-                if pooled:
-                    _launch("pcb_bn_act_max_bwd_reduce_bf16", R * C, dout.data_ptr(), arg.data_ptr(), y.data_ptr(),
-                            scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R // pool, pool,
-                            C, act, bsums.data_ptr())
+                if l in red_parts:
+                    parts, nparts = red_parts[l]
+                    sums_ptr = parts.data_ptr()
                 else:
-                    _launch("pcb_bn_act_bwd_reduce_bf16", R * C, dz.data_ptr(), y.data_ptr(), scale.data_ptr(),
-                            shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R, C, act, bsums.data_ptr())
-                _launch("pcb_bn_bwd_finalize", C, bsums.data_ptr(), R, C, scale.data_ptr(), mean.data_ptr(),
-                        invstd.data_ptr(), training, p.data_ptr(), q.data_ptr())
+                    nparts, sums_ptr = 1, bsums.data_ptr()
+                    if pooled:
+                        _launch("pcb_bn_act_max_bwd_reduce_bf16", R * C, dout.data_ptr(), arg.data_ptr(), y.data_ptr(),
+                                scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R // pool, pool,
+                                C, act, bsums.data_ptr())
+                    else:
+                        _launch("pcb_bn_act_bwd_reduce_bf16", R * C, dz.data_ptr(), y.data_ptr(), scale.data_ptr(),
+                                shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R, C, act, bsums.data_ptr())
+                _launch("pcb_bn_bwd_finalize", C, sums_ptr, nparts, R, C, scale.data_ptr(), mean.data_ptr(),
+                        invstd.data_ptr(), training, p.data_ptr(), q.data_ptr(), bsums.data_ptr())
                 apro = 3 if pooled else 2
                 a0 = 0 if pooled else dz.data_ptr()
                 dptr = dout.data_ptr() if pooled else 0
@@ -347,10 +354,21 @@ class _FusedStack(torch.autograd.Function):
                 if l or ctx.needs_input_grad[0]:
                     wt = wp.t().contiguous()  # [K, C]: row n = input column, contiguous over C
                     dprev = torch.empty(R, K, dtype=torch.bfloat16, device=dev)
-                    # algorithmic bytes: y (+ dz, or dout/argmax per group) in, dz_{l-1} out
-                    _launch("pcb_gemm_nt_bf16", (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                            p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, wt.data_ptr(), R, K, C,
-                            dprev.data_ptr(), 0)
+                    nbytes = (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K
+                    if l and K <= 128:
+                        # ... and, in its epilogue, the BatchNorm-backward sums of layer l-1
+                        ps = stats[l - 1]
+                        npr = lib.pcb_gemm_nt_partials(apro, R, K)
+                        parts = torch.empty(npr, 2, K, dtype=torch.float32, device=dev)
+                        _launch("pcb_gemm_nt_red_bf16", nbytes + 2 * R * K, apro, a0, y.data_ptr(), scale.data_ptr(),
+                                shift.data_ptr(), p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act,
+                                wt.data_ptr(), R, K, C, dprev.data_ptr(), ys[l - 1].data_ptr(), ps[2].data_ptr(),
+                                ps[3].data_ptr(), ps[4].data_ptr(), ps[5].data_ptr(), act, parts.data_ptr())
+                        red_parts[l - 1] = (parts, npr)
+                    else:
+                        _launch("pcb_gemm_nt_bf16", nbytes, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, wt.data_ptr(), R, K, C,
+                                dprev.data_ptr(), 0)
                 else:
                     dprev = None
                 # parameter gradients of this layer

@@ -13,13 +13,27 @@ def timeit(f, n=20, w=5):
 def nt(pro, R, K, N, stats, ns=16):
     x = torch.randn(R, K, device="cuda").to(torch.bfloat16); y = torch.randn(R, K, device="cuda").to(torch.bfloat16)
     w = torch.randn(N, K, device="cuda").to(torch.bfloat16); out = torch.empty(R, N, device="cuda", dtype=torch.bfloat16)
-    v = [torch.rand(K, device="cuda") for _ in range(4)]; sums = torch.zeros(2, N, device="cuda")
+    v = [torch.rand(K, device="cuda") for _ in range(4)]; sums = torch.zeros(L.pcb_gemm_nt_partials(pro, R, N), 2, N, device="cuda")
     dout = torch.randn(R // ns, K, device="cuda"); arg = torch.randint(0, ns, (R // ns, K), device="cuda", dtype=torch.uint8)
     f = lambda: L.pcb_gemm_nt_bf16(pro, x.data_ptr(), y.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
                                    dout.data_ptr(), arg.data_ptr(), ns, 1, w.data_ptr(), R, N, K, out.data_ptr(), sums.data_ptr() if stats else 0, st())
     us = timeit(f)
     byt = 2 * R * N + (2 * R * K if pro < 2 else 4 * R * K if pro == 2 else 2 * R * K + 5 * (R // ns) * K)
     print(f"nt pro={pro} stats={stats} R={R} K={K} N={N}: {us:8.1f} us  {byt / us / 1e6:6.2f} TB/s")
+def ntred(pro, R, K, N, ns=16):
+    x = torch.randn(R, K, device="cuda").to(torch.bfloat16); y = torch.randn(R, K, device="cuda").to(torch.bfloat16)
+    w = torch.randn(N, K, device="cuda").to(torch.bfloat16); out = torch.empty(R, N, device="cuda", dtype=torch.bfloat16)
+    yp = torch.randn(R, N, device="cuda").to(torch.bfloat16); rv = [torch.rand(N, device="cuda") for _ in range(4)]
+    v = [torch.rand(K, device="cuda") for _ in range(4)]; sums = torch.zeros(L.pcb_gemm_nt_partials(pro, R, N), 2, N, device="cuda")
+    dout = torch.randn(R // ns, K, device="cuda"); arg = torch.randint(0, ns, (R // ns, K), device="cuda", dtype=torch.uint8)
+    f = lambda: L.pcb_gemm_nt_red_bf16(pro, x.data_ptr(), y.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
+                                   dout.data_ptr(), arg.data_ptr(), ns, 1, w.data_ptr(), R, N, K, out.data_ptr(), yp.data_ptr(),
+                                   rv[0].data_ptr(), rv[1].data_ptr(), rv[2].data_ptr(), rv[3].data_ptr(), 1, sums.data_ptr(), st())
+    us = timeit(f)
+    byt = 4 * R * N + (4 * R * K if pro == 2 else 2 * R * K + 5 * (R // ns) * K)
+    print(f"nt RED pro={pro} R={R} K={K} N={N}: {us:8.1f} us  {byt / us / 1e6:6.2f} TB/s")
+for args in [(2, 524288, 64, 64), (2, 524288, 128, 64), (3, 524288, 128, 64), (3, 262144, 256, 128), (2, 262144, 128, 128)]:
+    ntred(*args)
 for args in [(0, 524288, 8, 64, 1), (1, 524288, 64, 64, 1), (1, 524288, 64, 128, 1), (2, 524288, 64, 64, 0), (2, 524288, 128, 64, 0),
              (3, 524288, 128, 64, 0), (2, 262144, 128, 264, 0), (2, 262144, 256, 264, 0), (1, 262144, 264, 128, 1), (0, 262144, 264, 128, 1)]:
     nt(*args)
