@@ -262,21 +262,34 @@ int pcb_gemm_nt_partials(int pro, long R, int N);
  * B' = x [R,N] (bpro 0) or act(x*xscale + xshift) (bpro 1).  M % 8 == 0, N % 8 == 0.
  * The rows are split over workgroups; each split stores its partial tile into `workspace`
  * (pcb_gemm_tn_workspace(R,M,N) floats, caller-owned) and a second kernel sums the slabs in a fixed
- * order, so the result is bitwise reproducible (no atomics). */
+ * order, so the result is bitwise reproducible (no atomics).
+ * Output layout: out_cols <= 0 gives dW [M, N].  out_cols = k > 0 gives dW [M, k] in the layer's
+ * REAL weight layout, dropping the padding of the row layout out_perm describes (perm of
+ * pcb_prep_weights_bf16) -- the gradient then needs no unpadding pass. */
 int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const float *scale, const float *shift,
                      const float *p, const float *q, const float *dout, const unsigned char *argmax,
                      int ns, int act, int bpro, const void *x, const float *xscale, const float *xshift,
-                     int xact, long R, int M, int N, float *workspace, float *dW, void *stream);
+                     int xact, long R, int M, int N, float *workspace, float *dW, int out_cols,
+                     int out_perm, void *stream);
 
 /* Number of fp32 elements pcb_gemm_tn_bf16 needs in `workspace` for these sizes. */
 long pcb_gemm_tn_workspace(long R, int M, int N);
 
 /* p, q of the fused BatchNorm backward from sums = [nparts][2][C] partial slabs of
  * (sum du, sum du*xhat): p = -scale*invstd*s2/rows, q = -scale*s1/rows - p*mean; zeros when
- * use_batch_stats == 0.  total [2][C] (optional) receives the slab totals (= dbeta, dgamma). */
+ * use_batch_stats == 0.  The parameter gradients the totals amount to are written to dgamma (= s2),
+ * dbeta (= s1) and dbias (0 under batch statistics, scale*s1 otherwise), [C] each, any may be NULL. */
 int pcb_bn_bwd_finalize(const float *sums, int nparts, long rows, int C, const float *scale,
                         const float *mean, const float *invstd, int use_batch_stats, float *p, float *q,
-                        float *total, void *stream);
+                        float *dgamma, float *dbeta, float *dbias, void *stream);
+
+/* bf16 GEMM operands of n <= 8 layers from their fp32 master weights, in one launch
+ * (replaces weight.view(Cout,Cin).to(bf16) / F.pad / .t().contiguous() per layer).
+ * desc = n x 8 int64 on the HOST: {w fp32 [C,k], wp bf16 [C,kp], wt bf16 [kp,C] or 0, C, k, kp, perm, 0}.
+ * perm names the column layout of the layer's input rows: 0 = real columns in place, zero padded;
+ * C > 0 = pcb_group_rows_bf16 rows (C feature columns, then the 3 centred coordinates);
+ * -D < 0 = interpolate+concat rows (first D columns in place, the rest from column pad8(D)). */
+int pcb_prep_weights_bf16(int n, const long long *desc, void *stream);
 
 /* pcb_gemm_nt_bf16 (pro 2 or 3, N <= 128) whose epilogue also accumulates the BatchNorm-backward
  * sums of the layer BELOW: the produced tile is that layer's dz; with its y (red_y [R,N] bf16) and

@@ -42,9 +42,10 @@ SIGNATURES = {
     "pcb_interp_csr_fill": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
     "pcb_interpolate_bwd_csr_bf16": [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "pcb_gemm_nt_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p],
-    "pcb_gemm_tn_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _p],
+    "pcb_gemm_tn_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _i, _i, _p],
     "pcb_gemm_tn_workspace": [_l, _i, _i],
-    "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p],
+    "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "pcb_prep_weights_bf16": [_i, _p, _p],
     "pcb_gemm_nt_red_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "pcb_bn_act_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],

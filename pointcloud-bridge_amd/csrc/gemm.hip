@@ -619,10 +619,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
         }
 }
 
-// dW[e] = sum over splits of part[s][e], in a fixed order (bitwise reproducible weight gradient).
+// Column layouts of a padded GEMM operand [.., kp] against the layer's real weight [.., k]
+// (host side: rowmlp.padded_weight_from).  Returns the real column a padded column j holds, or -1
+// for padding.
+//   perm = 0      real columns in place, zero padded on the right
+//   perm = C > 0  grouped rows (pcb_group_rows_bf16): the C feature columns first, then the 3
+//                 centred coordinates (real order: coordinates first)
+//   perm = -D < 0 interpolate+concat rows: the first D columns in place, the rest from pad8(D)
+__device__ __forceinline__ int real_column(int j, int k, int perm)
+{
+    if (perm > 0) return j < perm ? 3 + j : (j < perm + 3 ? j - perm : -1);
+    if (perm < 0) {
+        const int d = -perm, dp = (d + 7) & ~7;
+        if (j < d) return j;
+        const int r = d + (j - dp);
+        return (j >= dp && r < k) ? r : -1;
+    }
+    return j < k ? j : -1;
+}
+
+// dW = sum over splits of part[s], in a fixed order (bitwise reproducible weight gradient), written
+// in the real weight layout [M, k] (padding columns dropped, see real_column).
 // 64 consecutive elements x 16 split-lanes per workgroup: coalesced slab reads, LDS tree at the end.
 __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restrict__ part, int splits,
-                                                             long elems, float *__restrict__ dW)
+                                                             long elems, float *__restrict__ dW, int N, int k,
+                                                             int perm)
 {
     __shared__ float red[16][64];
     const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
@@ -636,22 +657,27 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restr
         if (sy == 0 && e < elems) {
             float t = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t += red[k][ex];
-            dW[e] = t;
+            for (int i = 0; i < 16; ++i) t += red[i][ex];
+            const long m = e / N;
+            const int r = real_column((int)(e - m * N), k, perm);
+            if (r >= 0) dW[m * k + r] = t;
         }
         __syncthreads();
     }
 }
 
 // p, q of the fused BatchNorm backward of one layer from sums = [nparts][2][C] partial slabs of
-// (sum du, sum du*xhat); the slab totals are also written to `total` [2][C] (= dbeta, dgamma).
+// (sum du, sum du*xhat); the parameter gradients the totals amount to go to dgamma, dbeta, dbias
+// ([C] each, optional): dbeta = s1, dgamma = s2, dbias = 0 under batch statistics (the mean
+// subtraction cancels a bias exactly), scale*s1 otherwise.
 // Block = 32 channels x 32 slab-lanes.
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ sums, int nparts,
                                                                 long rows, int C, const float *__restrict__ scale,
                                                                 const float *__restrict__ mean,
                                                                 const float *__restrict__ invstd,
                                                                 int use_batch_stats, float *__restrict__ p,
-                                                                float *__restrict__ q, float *__restrict__ total)
+                                                                float *__restrict__ q, float *__restrict__ dgamma,
+                                                                float *__restrict__ dbeta, float *__restrict__ dbias)
 {
     __shared__ float red[2][32][32];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
@@ -674,10 +700,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
         s1 += red[0][k][cl];
         s2 += red[1][k][cl];
     }
-    if (total) {
-        total[c] = s1;
-        total[C + c] = s2;
-    }
+    if (dgamma) dgamma[c] = s2;
+    if (dbeta) dbeta[c] = s1;
+    if (dbias) dbias[c] = use_batch_stats ? 0.0f : scale[c] * s1;
     if (!use_batch_stats) {
         p[c] = 0.0f;
         q[c] = 0.0f;
@@ -735,7 +760,7 @@ long tn_splits(long R, int M, int N, long *rows_per_split)
 
 template <int APRO>
 void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int N, float *part, float *dW,
-               hipStream_t st)
+               int out_cols, int out_perm, hipStream_t st)
 {
     long rps;
     const long splits = tn_splits(R, M, N, &rps);
@@ -747,7 +772,8 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
     const long elems = (long)M * N;
     long blocks = (elems + 63) / 64;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, part, (int)splits, elems, dW);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, part, (int)splits, elems, dW, N,
+                       out_cols, out_perm);
 }
 
 inline bool bad_dim(long v) { return v <= 0 || (v & 7) != 0; }
@@ -820,9 +846,11 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
                                 const float *shift, const float *p, const float *q, const float *dout,
                                 const unsigned char *argmax, int ns, int act, int bpro, const void *x,
                                 const float *xscale, const float *xshift, int xact, long R, int M, int N,
-                                float *workspace, float *dW, void *stream)
+                                float *workspace, float *dW, int out_cols, int out_perm, void *stream)
 {
     if (!x || !dW || !workspace || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (out_cols <= 0) { out_cols = N; out_perm = 0; }
+    if (out_cols > N) return PCB_ERR_INVALID_ARG;
     if (bad_dim(M) || bad_dim(N)) return PCB_ERR_UNSUPPORTED;
     if (apro != PRO_PLAIN && apro != PRO_DY && apro != PRO_DY_POOL) return PCB_ERR_INVALID_ARG;
     if (apro != PRO_PLAIN && (!y || !scale || !shift || !p || !q)) return PCB_ERR_INVALID_ARG;
@@ -833,11 +861,11 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
     const Operand B = make_operand(x, nullptr, N, xscale, xshift, nullptr, nullptr, nullptr, nullptr, 1, xact);
     hipStream_t st = (hipStream_t)stream;
     if (apro == PRO_PLAIN)
-        launch_tn<PRO_PLAIN>(A, B, bpro, R, M, N, workspace, dW, st);
+        launch_tn<PRO_PLAIN>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
     else if (apro == PRO_DY)
-        launch_tn<PRO_DY>(A, B, bpro, R, M, N, workspace, dW, st);
+        launch_tn<PRO_DY>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
     else
-        launch_tn<PRO_DY_POOL>(A, B, bpro, R, M, N, workspace, dW, st);
+        launch_tn<PRO_DY_POOL>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
     return pcb_check_launch();
 }
 
@@ -856,11 +884,64 @@ extern "C" long pcb_gemm_tn_workspace(long R, int M, int N)
 
 extern "C" int pcb_bn_bwd_finalize(const float *sums, int nparts, long rows, int C, const float *scale,
                                    const float *mean, const float *invstd, int use_batch_stats, float *p,
-                                   float *q, float *total, void *stream)
+                                   float *q, float *dgamma, float *dbeta, float *dbias, void *stream)
 {
     if (!sums || nparts < 1 || !scale || !mean || !invstd || !p || !q || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums,
-                       nparts, rows, C, scale, mean, invstd, use_batch_stats, p, q, total);
+                       nparts, rows, C, scale, mean, invstd, use_batch_stats, p, q, dgamma, dbeta, dbias);
+    return pcb_check_launch();
+}
+
+// ---- weight preparation -------------------------------------------------------------------------
+// The fp32 master weights of up to PREP_MAX layers become, in ONE launch, the bf16 operands the
+// GEMMs read: wp [C, kp] in the padded column layout of the layer's input rows (real_column) and,
+// for the input-gradient GEMM, its transpose wt [kp, C].
+namespace {
+constexpr int PREP_MAX = 8;
+struct PrepLayer {
+    const float *w;   // [C, k] fp32
+    u16 *wp;          // [C, kp] bf16
+    u16 *wt;          // [kp, C] bf16 or NULL
+    int C, k, kp, perm;
+};
+struct PrepArgs {
+    PrepLayer l[PREP_MAX];
+};
+
+__global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs args)
+{
+    const PrepLayer L = args.l[blockIdx.y];
+    const int total = L.C * L.kp;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int c = e / L.kp, j = e - c * L.kp;
+        const int r = real_column(j, L.k, L.perm);
+        const u16 h = r >= 0 ? f2bf(L.w[(long)c * L.k + r]) : (u16)0;
+        L.wp[e] = h;
+        if (L.wt) L.wt[(long)j * L.C + c] = h;
+    }
+}
+}  // namespace
+
+extern "C" int pcb_prep_weights_bf16(int n, const long long *desc, void *stream)
+{
+    if (n < 1 || n > PREP_MAX || !desc) return PCB_ERR_INVALID_ARG;
+    PrepArgs a;
+    int most = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long *d = desc + 8 * i;
+        a.l[i].w = (const float *)d[0];
+        a.l[i].wp = (u16 *)d[1];
+        a.l[i].wt = (u16 *)d[2];
+        a.l[i].C = (int)d[3];
+        a.l[i].k = (int)d[4];
+        a.l[i].kp = (int)d[5];
+        a.l[i].perm = (int)d[6];
+        if (!a.l[i].w || !a.l[i].wp || a.l[i].C <= 0 || a.l[i].k <= 0 || a.l[i].kp < a.l[i].k) return PCB_ERR_INVALID_ARG;
+        if (a.l[i].C * a.l[i].kp > most) most = a.l[i].C * a.l[i].kp;
+    }
+    int gx = (most + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
     return pcb_check_launch();
 }
 

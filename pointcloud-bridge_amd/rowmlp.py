@@ -254,29 +254,33 @@ class _FusedStack(torch.autograd.Function):
         dev = x.device
         R = x.shape[0]
         layers = [flat[i * _FusedStack.NPER:(i + 1) * _FusedStack.NPER] for i in range(L)]
-        ys, wps, stats = [], [], []
-        cur, cur_k = x, x.shape[1]
+        need_dx = x.requires_grad
         lib = _lib.load()
         with torch.cuda.device(dev):
+            # per-layer constants of all layers in ONE zero-filled buffer (one fill per stack):
+            # rows of layer l = unused(2) | scale | shift | mean | invstd | bsums(2) | p | q
+            widths = [t[0].shape[0] for t in layers]
+            stz = torch.zeros(10 * sum(widths), dtype=torch.float32, device=dev)
+            stats = _stat_views(stz, widths)
+            wps, wts = _prep_weights([t[0] for t in layers], x.shape[1], perm, need_dx, dev)
+            ys = []
+            cur, cur_k = x, x.shape[1]
             for l, (w, bias, gamma, beta, rm, rv, training, momentum, eps) in enumerate(layers):
-                C = w.shape[0]
-                wp = padded_weight_from(w, cur_k, perm if l == 0 else 0)
+                C = widths[l]
+                st = stats[l]
                 y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-                st = torch.zeros(10, C, dtype=torch.float32, device=dev)  # sums2|scale|shift|mean|invstd|bsums2|p|q
-                prev = stats[-1] if l else None
+                prev = stats[l - 1] if l else None
                 nparts = lib.pcb_gemm_nt_partials(1 if l else 0, R, C)
                 parts = torch.empty(nparts, 2, C, dtype=torch.float32, device=dev) if training else None
                 _launch("pcb_gemm_nt_bf16", 2 * R * (cur_k + C), 1 if l else 0, cur.data_ptr(), 0,
                         prev[2].data_ptr() if l else 0, prev[3].data_ptr() if l else 0, 0, 0, 0, 0, 0, act,
-                        wp.data_ptr(), R, C, cur_k, y.data_ptr(), parts.data_ptr() if training else 0)
+                        wps[l].data_ptr(), R, C, cur_k, y.data_ptr(), parts.data_ptr() if training else 0)
                 _launch("pcb_bn_finalize", C, parts.data_ptr() if training else 0, nparts, R, C,
                         0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
                         0 if bias is None else bias.data_ptr(), 0 if rm is None else rm.data_ptr(),
                         0 if rv is None else rv.data_ptr(), float(momentum), float(eps), int(training),
                         st[2].data_ptr(), st[3].data_ptr(), st[4].data_ptr(), st[5].data_ptr())
                 ys.append(y)
-                wps.append(wp)
-                stats.append(st)
                 cur, cur_k = y, C
             st = stats[-1]
             C = cur_k
@@ -291,17 +295,19 @@ class _FusedStack(torch.autograd.Function):
                 out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
                 _launch("pcb_bn_act_bf16", R * C, cur.data_ptr(), st[2].data_ptr(), st[3].data_ptr(), R, C, act,
                         out.data_ptr())
-        ctx.save_for_backward(x, arg, *ys, *wps, *stats)
+        ctx.save_for_backward(x, arg, stz, *ys, *wts)
         ctx.cfg = (act, pool, perm, L, [int(t[6]) for t in layers], [t[0].shape for t in layers],
-                   [t[1] is not None for t in layers], [t[2] is not None for t in layers])
+                   [t[1] is not None for t in layers], [t[2] is not None for t in layers], need_dx)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        act, pool, perm, L, trainings, wshapes, has_bias, has_affine = ctx.cfg
+        act, pool, perm, L, trainings, wshapes, has_bias, has_affine, had_wt0 = ctx.cfg
         saved = ctx.saved_tensors
-        x, arg = saved[0], saved[1]
-        ys, wps, stats = saved[2:2 + L], saved[2 + L:2 + 2 * L], saved[2 + 2 * L:2 + 3 * L]
+        x, arg, stz = saved[0], saved[1], saved[2]
+        ys, wts = saved[3:3 + L], saved[3 + L:3 + 2 * L]
+        widths = [ws[0] for ws in wshapes]
+        stats = _stat_views(stz, widths)
         dev = x.device
         R = x.shape[0]
         grads = [None] * (L * _FusedStack.NPER)
@@ -314,8 +320,9 @@ class _FusedStack(torch.autograd.Function):
             lib = _lib.load()
             red_parts = {}  # layer -> (partials, nparts) accumulated by the dgrad GEMM of the layer above
             for l in range(L - 1, -1, -1):
-                y, wp, st = ys[l], wps[l], stats[l]
-                C, K = wp.shape
+                y, st = ys[l], stats[l]
+                C = widths[l]
+                K = x.shape[1] if l == 0 else widths[l - 1]
                 training = trainings[l]
                 pooled = pool and l == L - 1
                 scale, shift, mean, invstd, bsums, p, q = st[2], st[3], st[4], st[5], st[6:8], st[8], st[9]
@@ -331,30 +338,43 @@ class _FusedStack(torch.autograd.Function):
                     else:
                         _launch("pcb_bn_act_bwd_reduce_bf16", R * C, dz.data_ptr(), y.data_ptr(), scale.data_ptr(),
                                 shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R, C, act, bsums.data_ptr())
+                # p, q of dy(dz, y) and, straight into fresh tensors, the BatchNorm/bias gradients
+                base = l * _FusedStack.NPER
+                dgamma = dbeta = dbias = None
+                if has_affine[l]:
+                    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+                    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+                    grads[base + 2], grads[base + 3] = dgamma, dbeta
+                if has_bias[l]:
+                    dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev)
                 _launch("pcb_bn_bwd_finalize", C, sums_ptr, nparts, R, C, scale.data_ptr(), mean.data_ptr(),
-                        invstd.data_ptr(), training, p.data_ptr(), q.data_ptr(), bsums.data_ptr())
+                        invstd.data_ptr(), training, p.data_ptr(), q.data_ptr(),
+                        0 if dgamma is None else dgamma.data_ptr(), 0 if dbeta is None else dbeta.data_ptr(),
+                        0 if dbias is None else dbias.data_ptr())
                 apro = 3 if pooled else 2
                 a0 = 0 if pooled else dz.data_ptr()
                 dptr = dout.data_ptr() if pooled else 0
                 aptr = arg.data_ptr() if pooled else 0
-                # weight gradient: dW = dy^T . x_l, with x_l = act(BN(y_{l-1})) recomputed on load
-                dwp = torch.empty(C, K, dtype=torch.float32, device=dev)
-                ws = torch.empty(_lib.load().pcb_gemm_tn_workspace(R, C, K), dtype=torch.float32, device=dev)
+                nbytes = (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K
+                # weight gradient: dW = dy^T . x_l, with x_l = act(BN(y_{l-1})) recomputed on load;
+                # written in the parameter's own [Cout, Cin] layout (padding dropped by the reduce)
+                k = wshapes[l][1]
+                dw = grads[base + 0] = torch.empty(wshapes[l], dtype=torch.float32, device=dev)
+                ws = torch.empty(lib.pcb_gemm_tn_workspace(R, C, K), dtype=torch.float32, device=dev)
                 if l:
                     ps = stats[l - 1]
-                    _launch("pcb_gemm_tn_bf16", (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                    _launch("pcb_gemm_tn_bf16", nbytes, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                             p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, 1,
                             ys[l - 1].data_ptr(), ps[2].data_ptr(), ps[3].data_ptr(), act, R, C, K, ws.data_ptr(),
-                            dwp.data_ptr())
+                            dw.data_ptr(), k, 0)
                 else:
-                    _launch("pcb_gemm_tn_bf16", (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                    _launch("pcb_gemm_tn_bf16", nbytes, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                             p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, 0, x.data_ptr(), 0, 0,
-                            0, R, C, K, ws.data_ptr(), dwp.data_ptr())
+                            0, R, C, K, ws.data_ptr(), dw.data_ptr(), k, perm)
                 # input gradient: dz_{l-1} = dy . W   (skipped for the first layer if x needs none)
-                if l or ctx.needs_input_grad[0]:
-                    wt = wp.t().contiguous()  # [K, C]: row n = input column, contiguous over C
+                if l or (ctx.needs_input_grad[0] and had_wt0):
+                    wt = wts[l]  # [K, C]: row n = input column, contiguous over C
                     dprev = torch.empty(R, K, dtype=torch.bfloat16, device=dev)
-                    nbytes = (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K
                     if l and K <= 128:
                         # ... and, in its epilogue, the BatchNorm-backward sums of layer l-1
                         ps = stats[l - 1]
@@ -371,19 +391,49 @@ class _FusedStack(torch.autograd.Function):
                                 dprev.data_ptr(), 0)
                 else:
                     dprev = None
-                # parameter gradients of this layer
-                k = wshapes[l][1]
-                dw = _unpad_weight_grad(dwp, k, perm if l == 0 else 0)
-                base = l * _FusedStack.NPER
-                grads[base + 0] = dw.reshape(wshapes[l])
-                if has_bias[l]:
-                    grads[base + 1] = (torch.zeros(C, dtype=torch.float32, device=dev) if training
-                                       else scale * bsums[0])
-                if has_affine[l]:
-                    grads[base + 2] = bsums[1]
-                    grads[base + 3] = bsums[0]
                 dz = dprev
         return (dz, None, None, None, None, *grads)
+
+
+def _stat_views(stz, widths):
+    """Per-layer [10, C] views of a stack's flat constants buffer."""
+    out, off = [], 0
+    for c in widths:
+        out.append(stz[off:off + 10 * c].view(10, c))
+        off += 10 * c
+    return out
+
+
+def _prep_weights(weights, k0p, perm, need_wt0, dev):
+    """bf16 GEMM operands of a stack's layers from the fp32 master weights, in one launch
+    (pcb_prep_weights_bf16): wp_l [C_l, Kp_l] in the column layout of the layer's input rows
+    (perm applies to layer 0, whose rows are k0p wide) and wt_l = wp_l^T for the input-gradient
+    GEMM (layer 0's only if need_wt0).  Returns (wps, wts); a missing wt is an empty tensor."""
+    import ctypes
+    n = len(weights)
+    dims, total = [], 0
+    kp = k0p
+    for l, w in enumerate(weights):
+        c = w.shape[0]
+        k = w.numel() // c
+        want_t = l > 0 or need_wt0
+        dims.append((c, k, kp, perm if l == 0 else 0, total, want_t))
+        total += c * kp * (2 if want_t else 1)
+        kp = c
+    buf = torch.empty(total, dtype=torch.bfloat16, device=dev)
+    base = buf.data_ptr()
+    wps, wts, desc = [], [], []
+    for w, (c, k, kp, pm, off, want_t) in zip(weights, dims):
+        if not (w.is_contiguous() and w.dtype == torch.float32):
+            raise TypeError("fused bf16 layers expect contiguous fp32 master weights")
+        wps.append(buf[off:off + c * kp].view(c, kp))
+        wts.append(buf[off + c * kp:off + 2 * c * kp].view(kp, c) if want_t else buf[0:0])
+        desc += [w.data_ptr(), base + 2 * off, (base + 2 * (off + c * kp)) if want_t else 0, c, k, kp, pm, 0]
+    for i in range(0, n, 8):
+        m = min(8, n - i)
+        arr = (ctypes.c_longlong * (8 * m))(*desc[8 * i:8 * (i + m)])
+        _launch("pcb_prep_weights_bf16", total, m, arr)
+    return wps, wts
 
 
 def _stack_fusable(convs, bns):
@@ -394,8 +444,15 @@ def _fused_stack(convs, bns, x, act, pool, perm):
     kp = x.shape[1] if perm != 0 else pad8(convs[0].in_channels)
     xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
     flat = []
+    # num_batches_tracked += 1 of all the stack's BatchNorms in one multi-tensor launch
+    # (nn.BatchNorm.forward does it per module); the count itself is only read when momentum=None
+    counted = [bn.num_batches_tracked for bn in bns
+               if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None
+               and bn.momentum is not None]
+    if counted:
+        torch._foreach_add_(counted, 1)
     for conv, bn in zip(convs, bns):
-        momentum = _bn_bookkeeping(bn)
+        momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
         training = bn.training or (bn.running_mean is None and bn.running_var is None)
         track = bn.track_running_stats and bn.running_mean is not None
         flat += [conv.weight, conv.bias, bn.weight, bn.bias,
@@ -493,7 +550,7 @@ class _LinearBias(torch.autograd.Function):
         sums = torch.zeros(2, npad, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _launch("pcb_gemm_tn_bf16", 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
-                    0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr())
+                    0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr(), 0, 0)
             if has_bias:
                 _launch("pcb_colstats_bf16", R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
         if rows is None:

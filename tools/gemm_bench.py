@@ -46,7 +46,7 @@ def tn(apro, bpro, R, M, N, ns=16):
     ws = torch.empty(L.pcb_gemm_tn_workspace(R, M, N), device="cuda"); dw = torch.empty(M, N, device="cuda")
     f = lambda: L.pcb_gemm_tn_bf16(apro, dz.data_ptr(), y.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
                                    dout.data_ptr(), arg.data_ptr(), ns, 1, bpro, xx.data_ptr(), xv[0].data_ptr(), xv[1].data_ptr(), 1, R, M, N,
-                                   ws.data_ptr(), dw.data_ptr(), st())
+                                   ws.data_ptr(), dw.data_ptr(), 0, 0, st())
     us = timeit(f)
     byt = 2 * R * N + (2 * R * M if apro == 0 else 4 * R * M if apro == 2 else 2 * R * M + 5 * (R // ns) * M)
     print(f"tn apro={apro} bpro={bpro} R={R} M={M} N={N}: {us:8.1f} us  {byt / us / 1e6:6.2f} TB/s  ws={ws.numel()*4/1e6:.1f}MB")
