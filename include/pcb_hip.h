@@ -278,8 +278,10 @@ long pcb_gemm_tn_workspace(long R, int M, int N);
 /* p, q of the fused BatchNorm backward from sums = [nparts][2][C] partial slabs of
  * (sum du, sum du*xhat): p = -scale*invstd*s2/rows, q = -scale*s1/rows - p*mean; zeros when
  * use_batch_stats == 0.  The parameter gradients the totals amount to are written to dgamma (= s2),
- * dbeta (= s1) and dbias (0 under batch statistics, scale*s1 otherwise), [C] each, any may be NULL. */
-int pcb_bn_bwd_finalize(const float *sums, int nparts, long rows, int C, const float *scale,
+ * dbeta (= s1) and dbias (0 under batch statistics, scale*s1 otherwise), [C] each, any may be NULL.
+ * With nparts == 1 (a slab the reduce kernels accumulated into with atomics) the slab is cleared
+ * after use, ready for the next accumulation. */
+int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *scale,
                         const float *mean, const float *invstd, int use_batch_stats, float *p, float *q,
                         float *dgamma, float *dbeta, float *dbias, void *stream);
 
@@ -335,6 +337,54 @@ int pcb_interp_csr_fill(const int64_t *idx, int B, int N, int S, int k, const lo
 int pcb_interpolate_bwd_csr_bf16(const void *grad_rows, int ld, int col0, const float *w, const long *offsets,
                                  const int *entries, int B, int N, int S, int C, int k, void *grad_feat,
                                  void *stream);
+
+/*
+ * A whole stack of L <= PCB_STACK_MAX_LAYERS shared-MLP layers  x -> act(BN(x W^T + b))  [-> max over
+ * each `pool` consecutive rows]  enqueued from ONE call -- the loop the reference writes as
+ *   for i, conv in enumerate(self.mlp_convs): new_points = F.relu(self.mlp_bns[i](conv(new_points)))
+ *   new_points = torch.max(new_points, 2)[0]
+ * (models/pointnet2_utils.py:149-154, :207-209, :353-356; models/DGCNN.py:134-148).  The calls are
+ * exactly the sequence of pcb_prep_weights_bf16 / pcb_gemm_nt_bf16 / pcb_bn_finalize /
+ * pcb_bn_act(_max)_bf16 (forward) and pcb_bn_act(_max)_bwd_reduce_bf16 / pcb_bn_bwd_finalize /
+ * pcb_gemm_tn_bf16 / pcb_gemm_nt(_red)_bf16 (backward) a caller would issue itself; issuing them
+ * from native code keeps the host ahead of the GPU (one foreign call per stack and direction).
+ *
+ * desc: L x 16 int64 on the HOST, per layer
+ *   [0] w fp32 [C,k]  [1] conv bias [C] or 0  [2] gamma or 0  [3] beta or 0
+ *   [4] running_mean or 0  [5] running_var or 0  [6] C (multiple of 8)  [7] k = real input columns
+ *   [8] 1: batch statistics (training), 0: running statistics
+ *   [9] y bf16 [R,C]: the layer's pre-BatchNorm GEMM output (written by forward, read by backward)
+ *   [10] dW fp32 [C,k]  [11] dgamma [C]  [12] dbeta [C]  [13] dbias [C]   (backward outputs, any may be 0)
+ * fdesc: L x 2 doubles: momentum, eps.
+ * x bf16 [R,Kp] rows in the column layout `perm` (see pcb_prep_weights_bf16); act 0/1/2;
+ * pool = 0 (out bf16 [R,C_last]) or ns (out bf16 [R/ns,C_last] + argmax uint8).
+ * Caller-owned scratch shared by forward and backward of the same stack:
+ *   wbuf  bf16, pcb_mlp_stack_wbuf_elems(L,desc,Kp,need_wt0) elements (prepared weights; need_wt0 = the
+ *         input gradient dx will be wanted);   stz fp32 [10 * sum C] (per-layer constants);
+ *   parts fp32, >= 2 * C * pcb_gemm_nt_partials(pro,R,C) for every layer (statistics slabs).
+ * Backward only: g = dz bf16 [R,C_last] (pool 0) or dout fp32 [R/ns,C_last]; workspace fp32, >= the
+ * largest pcb_gemm_tn_workspace(R,C,Kp_l); dzbuf bf16 [2][R][max width] (L > 1); dx bf16 [R,Kp] or NULL.
+ */
+#define PCB_STACK_MAX_LAYERS 16
+long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, int need_wt0);
+int pcb_mlp_stack_forward(int L, const long long *desc, const double *fdesc, const void *x, long R, int Kp,
+                          int perm, int act, int pool, int need_wt0, void *wbuf, float *stz, float *parts,
+                          void *out, unsigned char *argmax, void *stream);
+int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const void *g,
+                           const unsigned char *argmax, long R, int Kp, int perm, int act, int pool,
+                           int need_wt0, const void *wbuf, float *stz, float *parts, float *workspace,
+                           void *dzbuf, void *dx, void *stream);
+
+/*
+ * HIP-event timing of the gemm_nt kernel family (pcb_gemm_nt_bf16 / pcb_gemm_nt_red_bf16, also when
+ * issued by the stack calls) on the stream they are launched on -- bench.py's roofline figure.
+ * pcb_timer_start arms and clears; pcb_timer_enable(0/1) pauses/resumes sampling; pcb_timer_stop
+ * synchronises the recorded events and returns launches, their summed duration and their
+ * algorithmic HBM bytes (A operand as read by its prologue + bf16 output [+ y for the RED variant]).
+ */
+int pcb_timer_start(void);
+int pcb_timer_enable(int on);
+int pcb_timer_stop(long *launches, double *milliseconds, double *bytes);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,12 @@ SIGNATURES = {
     "pcb_gemm_tn_workspace": [_l, _i, _i],
     "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "pcb_prep_weights_bf16": [_i, _p, _p],
+    "pcb_mlp_stack_wbuf_elems": [_i, _p, _i, _i],
+    "pcb_mlp_stack_forward": [_i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "pcb_mlp_stack_backward": [_i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "pcb_timer_start": [],
+    "pcb_timer_enable": [_i],
+    "pcb_timer_stop": [_p, _p, _p],
     "pcb_gemm_nt_red_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "pcb_bn_act_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
@@ -72,7 +78,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the build lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "pcb_status_string"
-                          else ctypes.c_long if name == "pcb_gemm_tn_workspace" else ctypes.c_int)
+                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems")
+                          else ctypes.c_int)
         _lib = lib
     return _lib
 

@@ -671,7 +671,7 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restr
 // ([C] each, optional): dbeta = s1, dgamma = s2, dbias = 0 under batch statistics (the mean
 // subtraction cancels a bias exactly), scale*s1 otherwise.
 // Block = 32 channels x 32 slab-lanes.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ sums, int nparts,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(float *__restrict__ sums, int nparts,
                                                                 long rows, int C, const float *__restrict__ scale,
                                                                 const float *__restrict__ mean,
                                                                 const float *__restrict__ invstd,
@@ -699,6 +699,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
     for (int k = 0; k < 32; ++k) {
         s1 += red[0][k][cl];
         s2 += red[1][k][cl];
+    }
+    if (nparts == 1) {
+        // a single slab was accumulated with atomics: leave it cleared for the next accumulation
+        sums[c] = 0.0f;
+        sums[C + c] = 0.0f;
     }
     if (dgamma) dgamma[c] = s2;
     if (dbeta) dbeta[c] = s1;
@@ -778,6 +783,16 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
 
 inline bool bad_dim(long v) { return v <= 0 || (v & 7) != 0; }
 
+// Algorithmic HBM bytes of one gemm_nt launch: the A operand as its prologue reads it + the bf16
+// output (the weights, a few KB, are not counted).  This is the figure bench.py's roofline uses.
+inline double nt_bytes(int pro, long R, int N, int K, int ns)
+{
+    double a = 2.0 * R * K;
+    if (pro == PRO_DY) a = 4.0 * R * K;
+    if (pro == PRO_DY_POOL) a = 2.0 * R * K + 5.0 * (double)(R / (ns > 0 ? ns : 1)) * K;
+    return a + 2.0 * R * N;
+}
+
 }  // namespace
 
 // A-operand description shared by the C entry points (all pointers may be NULL where unused):
@@ -816,6 +831,9 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
     if (pro == PRO_DY_POOL && (!dout || !argmax || ns <= 0 || ns > 255)) return PCB_ERR_INVALID_ARG;
     const Operand A = make_operand(a0, a1, K, scale, shift, p, q, dout, argmax, ns, act);
     hipStream_t st = (hipStream_t)stream;
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
+    const double bytes = nt_bytes(pro, R, N, K, ns);
     if (pro >= PRO_DY && !sums && N > NT_BN && K <= 256) {
         // wide input gradient: transformed A tile resident in LDS, column tiles walked inside
         const long tiles = (R + AR_BM - 1) / AR_BM;
@@ -831,6 +849,7 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
             else
                 hipLaunchKernelGGL((gemm_nt_ares_kernel<PRO_DY_POOL, 32>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out);
         }
+        pcb_timer_end(st, timed, bytes);
         return pcb_check_launch();
     }
     switch (pro) {
@@ -839,6 +858,7 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
         case PRO_DY: launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
         default: launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
     }
+    pcb_timer_end(st, timed, bytes);
     return pcb_check_launch();
 }
 
@@ -882,7 +902,7 @@ extern "C" long pcb_gemm_tn_workspace(long R, int M, int N)
     return tn_splits(R, M, N, &rps) * (long)M * N;
 }
 
-extern "C" int pcb_bn_bwd_finalize(const float *sums, int nparts, long rows, int C, const float *scale,
+extern "C" int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *scale,
                                    const float *mean, const float *invstd, int use_batch_stats, float *p,
                                    float *q, float *dgamma, float *dbeta, float *dbias, void *stream)
 {
@@ -965,9 +985,12 @@ extern "C" int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, con
     const Operand A = make_operand(a0, a1, K, scale, shift, p, q, dout, argmax, ns, act);
     const RedArgs red = {(const u16 *)red_y, red_scale, red_shift, red_mean, red_invstd, red_act};
     hipStream_t st = (hipStream_t)stream;
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
     if (pro == PRO_DY)
         launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, st, &red);
     else
         launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, st, &red);
+    pcb_timer_end(st, timed, nt_bytes(pro, R, N, K, ns) + 2.0 * R * N);
     return pcb_check_launch();
 }

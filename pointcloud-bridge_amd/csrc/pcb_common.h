@@ -82,6 +82,10 @@ __device__ __forceinline__ int clamp_index(int64_t j, int n)
     return (int)(j < 0 ? 0 : (j > (int64_t)(n - 1) ? (int64_t)(n - 1) : j));
 }
 
+// roofline timer hooks (stack.hip): no-ops unless pcb_timer_start armed the timer
+void pcb_timer_begin(hipStream_t st, hipEvent_t *stop);
+void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes);
+
 static inline int pcb_check_launch()
 {
     return hipGetLastError() == hipSuccess ? PCB_OK : PCB_ERR_LAUNCH;

@@ -1,0 +1,317 @@
+// Host-side runtime of the shared pointwise MLP stacks (see include/pcb_hip.h):
+//
+//   pcb_mlp_stack_forward / pcb_mlp_stack_backward   enqueue ALL kernels of a stack of
+//       Conv(1x1) -> BatchNorm -> activation layers [-> max over the neighbour axis] -- the loop
+//       the reference writes as `for i, conv in enumerate(self.mlp_convs): x = F.relu(bn(conv(x)))`
+//       (models/pointnet2_utils.py:149-154, :207-209, :353-356; models/DGCNN.py:134-148) -- from
+//       one call, so the host pays one foreign call per stack and direction instead of one per
+//       kernel (a PointNet++ MSG step has ~260 such launches; at ~20 us of interpreter time each
+//       they would out-last the GPU work).
+//   pcb_timer_*   HIP-event timing of the roofline kernel family (the gemm_nt launches) on the
+//       stream they are launched on, for bench.py.
+//
+// No device code here: everything goes through the entry points of gemm.hip / rowbn.hip.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "pcb_common.h"
+
+// ---- roofline timer -------------------------------------------------------------------------
+namespace {
+struct Timer {
+    std::mutex mu;
+    bool armed = false;    // between pcb_timer_start and pcb_timer_stop
+    bool on = false;       // sampling enabled right now
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> pool;
+    double bytes = 0.0;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+} g_timer;
+}  // namespace
+
+// called by the gemm_nt entry points around their launch
+void pcb_timer_begin(hipStream_t st, hipEvent_t *stop)
+{
+    *stop = nullptr;
+    if (!g_timer.on) return;
+    std::lock_guard<std::mutex> lk(g_timer.mu);
+    if (!g_timer.on) return;
+    hipEvent_t a = g_timer.get(), b = g_timer.get();
+    if (!a || !b) return;
+    (void)hipEventRecord(a, st);
+    g_timer.events.emplace_back(a, b);
+    *stop = b;
+}
+
+void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes)
+{
+    if (!stop) return;
+    (void)hipEventRecord(stop, st);
+    std::lock_guard<std::mutex> lk(g_timer.mu);
+    g_timer.bytes += bytes;
+}
+
+extern "C" int pcb_timer_start(void)
+{
+    std::lock_guard<std::mutex> lk(g_timer.mu);
+    for (auto &p : g_timer.events) {
+        g_timer.pool.push_back(p.first);
+        g_timer.pool.push_back(p.second);
+    }
+    g_timer.events.clear();
+    g_timer.bytes = 0.0;
+    g_timer.armed = true;
+    g_timer.on = true;
+    return PCB_OK;
+}
+
+extern "C" int pcb_timer_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_timer.mu);
+    g_timer.on = g_timer.armed && on != 0;
+    return PCB_OK;
+}
+
+extern "C" int pcb_timer_stop(long *launches, double *milliseconds, double *bytes)
+{
+    std::lock_guard<std::mutex> lk(g_timer.mu);
+    g_timer.on = false;
+    g_timer.armed = false;
+    double ms = 0.0;
+    long n = 0;
+    for (auto &p : g_timer.events) {
+        float t = 0.0f;
+        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) {
+            ms += t;
+            ++n;
+        }
+        g_timer.pool.push_back(p.first);
+        g_timer.pool.push_back(p.second);
+    }
+    g_timer.events.clear();
+    if (launches) *launches = n;
+    if (milliseconds) *milliseconds = ms;
+    if (bytes) *bytes = g_timer.bytes;
+    return PCB_OK;
+}
+
+// ---- stack descriptors ------------------------------------------------------------------------
+namespace {
+constexpr int kSlots = 16;  // int64 slots per layer, see include/pcb_hip.h
+enum { S_W = 0, S_BIAS, S_GAMMA, S_BETA, S_RMEAN, S_RVAR, S_C, S_K, S_TRAIN, S_Y, S_DW, S_DGAMMA, S_DBETA, S_DBIAS };
+
+struct Layer {
+    const float *w, *bias, *gamma, *beta;
+    float *rmean, *rvar;
+    int C, k, training;
+    void *y;
+    float *dW, *dgamma, *dbeta, *dbias;
+    int kp;          // padded input width (= previous layer's C, or the stack's Kp)
+    long wp_off;     // element offsets into the bf16 weight buffer
+    long wt_off;     // -1: no transposed copy
+    long st_off;     // float offset of this layer's [10][C] constants
+};
+
+template <typename T>
+T *ptr(long long v) { return reinterpret_cast<T *>(static_cast<uintptr_t>(v)); }
+
+int parse(int L, const long long *desc, int Kp, int need_wt0, Layer *out)
+{
+    if (L < 1 || L > PCB_STACK_MAX_LAYERS || !desc) return PCB_ERR_INVALID_ARG;
+    long woff = 0, soff = 0;
+    int kp = Kp;
+    for (int l = 0; l < L; ++l) {
+        const long long *d = desc + (long)kSlots * l;
+        Layer &a = out[l];
+        a.w = ptr<const float>(d[S_W]);
+        a.bias = ptr<const float>(d[S_BIAS]);
+        a.gamma = ptr<const float>(d[S_GAMMA]);
+        a.beta = ptr<const float>(d[S_BETA]);
+        a.rmean = ptr<float>(d[S_RMEAN]);
+        a.rvar = ptr<float>(d[S_RVAR]);
+        a.C = (int)d[S_C];
+        a.k = (int)d[S_K];
+        a.training = (int)d[S_TRAIN];
+        a.y = ptr<void>(d[S_Y]);
+        a.dW = ptr<float>(d[S_DW]);
+        a.dgamma = ptr<float>(d[S_DGAMMA]);
+        a.dbeta = ptr<float>(d[S_DBETA]);
+        a.dbias = ptr<float>(d[S_DBIAS]);
+        if (!a.w || !a.y || a.C <= 0 || (a.C & 7) || a.k <= 0 || a.k > kp || (kp & 7)) return PCB_ERR_INVALID_ARG;
+        a.kp = kp;
+        a.wp_off = woff;
+        woff += (long)a.C * kp;
+        if (l > 0 || need_wt0) {
+            a.wt_off = woff;
+            woff += (long)a.C * kp;
+        } else {
+            a.wt_off = -1;
+        }
+        a.st_off = soff;
+        soff += 10L * a.C;
+        kp = a.C;
+    }
+    return PCB_OK;
+}
+
+inline float *row(float *stz, const Layer &a, int r) { return stz + a.st_off + (long)r * a.C; }
+}  // namespace
+
+#define PCB_TRY(expr)                \
+    do {                             \
+        const int s_ = (expr);       \
+        if (s_ < 0) return s_;       \
+    } while (0)
+
+extern "C" long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, int need_wt0)
+{
+    if (L < 1 || L > PCB_STACK_MAX_LAYERS || !desc) return 0;
+    long total = 0;
+    int kp = Kp;
+    for (int l = 0; l < L; ++l) {
+        const int C = (int)desc[(long)kSlots * l + S_C];
+        total += (long)C * kp * ((l > 0 || need_wt0) ? 2 : 1);
+        kp = C;
+    }
+    return total;
+}
+
+extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double *fdesc, const void *x, long R,
+                                     int Kp, int perm, int act, int pool, int need_wt0, void *wbuf, float *stz,
+                                     float *parts, void *out, unsigned char *argmax, void *stream)
+{
+    Layer ly[PCB_STACK_MAX_LAYERS];
+    PCB_TRY(parse(L, desc, Kp, need_wt0, ly));
+    if (!fdesc || !x || !wbuf || !stz || !out || R <= 0 || pool < 0 || (pool && (!argmax || R % pool))) return PCB_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short *wb = (unsigned short *)wbuf;
+
+    long stz_floats = 0;
+    for (int l = 0; l < L; ++l) stz_floats += 10L * ly[l].C;
+    if (hipMemsetAsync(stz, 0, stz_floats * sizeof(float), st) != hipSuccess) return PCB_ERR_LAUNCH;
+
+    // bf16 operands of all layers (chunks of 8 layers per launch)
+    for (int l0 = 0; l0 < L; l0 += 8) {
+        const int n = L - l0 < 8 ? L - l0 : 8;
+        long long pd[8 * 8];
+        for (int i = 0; i < n; ++i) {
+            const Layer &a = ly[l0 + i];
+            long long *d = pd + 8 * i;
+            d[0] = (long long)(uintptr_t)a.w;
+            d[1] = (long long)(uintptr_t)(wb + a.wp_off);
+            d[2] = a.wt_off >= 0 ? (long long)(uintptr_t)(wb + a.wt_off) : 0;
+            d[3] = a.C;
+            d[4] = a.k;
+            d[5] = a.kp;
+            d[6] = (l0 + i == 0) ? perm : 0;
+            d[7] = 0;
+        }
+        PCB_TRY(pcb_prep_weights_bf16(n, pd, stream));
+    }
+
+    const void *cur = x;
+    for (int l = 0; l < L; ++l) {
+        const Layer &a = ly[l];
+        const bool stats = a.training != 0;
+        if (stats && !parts) return PCB_ERR_INVALID_ARG;
+        const float *pscale = l ? row(stz, ly[l - 1], 2) : nullptr;
+        const float *pshift = l ? row(stz, ly[l - 1], 3) : nullptr;
+        PCB_TRY(pcb_gemm_nt_bf16(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0, act,
+                                 wb + a.wp_off, R, a.C, a.kp, a.y, stats ? parts : nullptr, stream));
+        const int nparts = pcb_gemm_nt_partials(l ? 1 : 0, R, a.C);
+        PCB_TRY(pcb_bn_finalize(stats ? parts : nullptr, nparts, R, a.C, a.gamma, a.beta, a.bias, a.rmean, a.rvar,
+                                (float)fdesc[2 * l], (float)fdesc[2 * l + 1], a.training, row(stz, a, 2),
+                                row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), stream));
+        cur = a.y;
+    }
+    const Layer &last = ly[L - 1];
+    if (pool)
+        PCB_TRY(pcb_bn_act_max_bf16(cur, row(stz, last, 2), row(stz, last, 3), R / pool, pool, last.C, act, out, argmax,
+                                    stream));
+    else
+        PCB_TRY(pcb_bn_act_bf16(cur, row(stz, last, 2), row(stz, last, 3), R, last.C, act, out, stream));
+    return PCB_OK;
+}
+
+extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const void *g,
+                                      const unsigned char *argmax, long R, int Kp, int perm, int act, int pool,
+                                      int need_wt0, const void *wbuf, float *stz, float *parts, float *workspace,
+                                      void *dzbuf, void *dx, void *stream)
+{
+    Layer ly[PCB_STACK_MAX_LAYERS];
+    PCB_TRY(parse(L, desc, Kp, need_wt0, ly));
+    if (!x || !g || !wbuf || !stz || !workspace || R <= 0 || (pool && !argmax)) return PCB_ERR_INVALID_ARG;
+    if (dx && !need_wt0) return PCB_ERR_INVALID_ARG;
+    const unsigned short *wb = (const unsigned short *)wbuf;
+    int maxw = Kp;
+    for (int l = 0; l + 1 < L; ++l) maxw = ly[l].C > maxw ? ly[l].C : maxw;
+    if (L > 1 && !dzbuf) return PCB_ERR_INVALID_ARG;
+
+    const void *dz = pool ? nullptr : g;                 // dense upstream gradient (bf16 rows)
+    const float *dout = pool ? (const float *)g : nullptr;  // pooled upstream gradient (fp32)
+    bool have_parts = false;  // sums of layer l already accumulated by the dgrad GEMM of layer l+1
+    int have_nparts = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        const Layer &a = ly[l];
+        const bool pooled = pool && l == L - 1;
+        float *scale = row(stz, a, 2), *shift = row(stz, a, 3), *mean = row(stz, a, 4), *invstd = row(stz, a, 5);
+        float *bsums = row(stz, a, 6), *p = row(stz, a, 8), *q = row(stz, a, 9);
+        float *sums = bsums;
+        int nparts = 1;
+        if (have_parts) {
+            sums = parts;
+            nparts = have_nparts;
+        } else if (pooled) {
+            PCB_TRY(pcb_bn_act_max_bwd_reduce_bf16(dout, argmax, a.y, scale, shift, mean, invstd, R / pool, pool, a.C,
+                                                   act, bsums, stream));
+        } else {
+            PCB_TRY(pcb_bn_act_bwd_reduce_bf16(dz, a.y, scale, shift, mean, invstd, R, a.C, act, bsums, stream));
+        }
+        PCB_TRY(pcb_bn_bwd_finalize(sums, nparts, R, a.C, scale, mean, invstd, a.training, p, q, a.dgamma, a.dbeta,
+                                    a.dbias, stream));
+        have_parts = false;
+        const int apro = pooled ? 3 : 2;
+        const int ns = pooled ? pool : 1;
+        // weight gradient, in the parameter's own layout
+        if (a.dW) {
+            if (l) {
+                const Layer &b = ly[l - 1];
+                PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 1, b.y, row(stz, b, 2),
+                                         row(stz, b, 3), act, R, a.C, a.kp, workspace, a.dW, a.k, 0, stream));
+            } else {
+                PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 0, x, nullptr, nullptr,
+                                         0, R, a.C, a.kp, workspace, a.dW, a.k, perm, stream));
+            }
+        }
+        // input gradient
+        if (l == 0 && !dx) break;
+        void *dprev = l ? (void *)((unsigned short *)dzbuf + (long)(l & 1) * R * maxw) : dx;
+        const unsigned short *wt = wb + a.wt_off;
+        if (l && a.kp <= 128 && parts) {
+            const Layer &b = ly[l - 1];
+            PCB_TRY(pcb_gemm_nt_red_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C, dprev,
+                                         b.y, row(stz, b, 2), row(stz, b, 3), row(stz, b, 4), row(stz, b, 5), act, parts,
+                                         stream));
+            have_parts = true;
+            have_nparts = pcb_gemm_nt_partials(apro, R, a.kp);
+        } else {
+            PCB_TRY(pcb_gemm_nt_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C, dprev,
+                                     nullptr, stream));
+        }
+        dz = dprev;
+        dout = nullptr;
+    }
+    return PCB_OK;
+}

@@ -18,47 +18,32 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# Optional live timing of ONE entry point (bench.py's roofline leg): HIP events are recorded on the
-# stream the kernel is launched on (torch's current stream) around every launch of that entry point.
-_timer = None
-
-
-def kernel_timer_start(name):
-    """Start recording (event pairs, work units) for every launch of C-ABI entry point `name`."""
-    global _timer
-    _timer = {"name": name, "events": [], "units": 0, "on": True}
+# Live timing of the roofline kernel family (bench.py): libpcb_hip.so records HIP events on the
+# launch stream around every gemm_nt launch (pcb_timer_* in include/pcb_hip.h), whether the launch
+# comes from Python or from the native stack runtime.
+def kernel_timer_start():
+    """Arm the library's gemm_nt timer (clears earlier samples)."""
+    _lib.check(_lib.load().pcb_timer_start(), "pcb_timer_start")
 
 
 def kernel_timer_enable(flag):
-    """Pause / resume event recording (bench.py samples one step in five: an event pair around every
+    """Pause / resume sampling (bench.py samples one step in five: an event pair around every
     launch costs microseconds of its own, which must not leak into the throughput figure)."""
-    if _timer is not None:
-        _timer["on"] = bool(flag)
+    _lib.load().pcb_timer_enable(int(bool(flag)))
 
 
 def kernel_timer_stop():
-    """-> (launches, total milliseconds, total work units) since kernel_timer_start; synchronises."""
-    global _timer
-    t, _timer = _timer, None
-    if t is None:
-        return 0, 0.0, 0
-    torch.cuda.synchronize()
-    return len(t["events"]), sum(a.elapsed_time(b) for a, b in t["events"]), t["units"]
+    """-> (launches, total milliseconds, algorithmic bytes) since kernel_timer_start; synchronises."""
+    import ctypes
+    n, ms, by = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _lib.check(_lib.load().pcb_timer_stop(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), "pcb_timer_stop")
+    return n.value, ms.value, by.value
 
 
 def _launch(name, units, *args):
-    """Call entry point `name` of libpcb_hip.so on the current stream; raise on a bad status."""
-    fn = getattr(_lib.load(), name)
-    t = _timer
-    if t is not None and t["on"] and t["name"] == name:
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        status = fn(*args, _stream())
-        b.record()
-        t["events"].append((a, b))
-        t["units"] += units
-    else:
-        status = fn(*args, _stream())
+    """Call entry point `name` of libpcb_hip.so on the current stream; raise on a bad status.
+    (`units` documents the call's work at the call site; timing lives in the library.)"""
+    status = getattr(_lib.load(), name)(*args, _stream())
     _lib.check(status, name)
 
 

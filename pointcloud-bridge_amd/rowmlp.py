@@ -15,6 +15,8 @@ Two numerically distinct execution modes, selected with `set_precision`:
 Both modes read the parameters of the caller's stock nn.Conv*/nn.BatchNorm* modules and keep their
 running statistics exactly as nn.BatchNorm does, so state_dicts stay interchangeable.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -252,188 +254,96 @@ class _FusedStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act, pool, perm, L, *flat):
         dev = x.device
-        R = x.shape[0]
+        R, Kp = x.shape
         layers = [flat[i * _FusedStack.NPER:(i + 1) * _FusedStack.NPER] for i in range(L)]
-        need_dx = x.requires_grad
+        need_dx = bool(x.requires_grad)
+        widths = [t[0].shape[0] for t in layers]
         lib = _lib.load()
+        # caller-owned buffers of pcb_mlp_stack_forward/backward (include/pcb_hip.h)
+        ybuf = torch.empty(R * sum(widths), dtype=torch.bfloat16, device=dev)
+        stz = torch.empty(10 * sum(widths), dtype=torch.float32, device=dev)
+        parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
+        desc = _stack_desc(layers, widths, ybuf, R)
+        wbuf = torch.empty(lib.pcb_mlp_stack_wbuf_elems(L, desc, Kp, int(need_dx)), dtype=torch.bfloat16, device=dev)
+        fdesc = (ctypes.c_double * (2 * L))(*[float(v) for t in layers for v in (t[7], t[8])])
+        C = widths[-1]
+        if pool:
+            out = torch.empty(R // pool, C, dtype=torch.bfloat16, device=dev)
+            arg = torch.empty(R // pool, C, dtype=torch.uint8, device=dev)
+        else:
+            out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+            arg = None
         with torch.cuda.device(dev):
-            # per-layer constants of all layers in ONE zero-filled buffer (one fill per stack):
-            # rows of layer l = unused(2) | scale | shift | mean | invstd | bsums(2) | p | q
-            widths = [t[0].shape[0] for t in layers]
-            stz = torch.zeros(10 * sum(widths), dtype=torch.float32, device=dev)
-            stats = _stat_views(stz, widths)
-            wps, wts = _prep_weights([t[0] for t in layers], x.shape[1], perm, need_dx, dev)
-            ys = []
-            cur, cur_k = x, x.shape[1]
-            for l, (w, bias, gamma, beta, rm, rv, training, momentum, eps) in enumerate(layers):
-                C = widths[l]
-                st = stats[l]
-                y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-                prev = stats[l - 1] if l else None
-                nparts = lib.pcb_gemm_nt_partials(1 if l else 0, R, C)
-                parts = torch.empty(nparts, 2, C, dtype=torch.float32, device=dev) if training else None
-                _launch("pcb_gemm_nt_bf16", 2 * R * (cur_k + C), 1 if l else 0, cur.data_ptr(), 0,
-                        prev[2].data_ptr() if l else 0, prev[3].data_ptr() if l else 0, 0, 0, 0, 0, 0, act,
-                        wps[l].data_ptr(), R, C, cur_k, y.data_ptr(), parts.data_ptr() if training else 0)
-                _launch("pcb_bn_finalize", C, parts.data_ptr() if training else 0, nparts, R, C,
-                        0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
-                        0 if bias is None else bias.data_ptr(), 0 if rm is None else rm.data_ptr(),
-                        0 if rv is None else rv.data_ptr(), float(momentum), float(eps), int(training),
-                        st[2].data_ptr(), st[3].data_ptr(), st[4].data_ptr(), st[5].data_ptr())
-                ys.append(y)
-                cur, cur_k = y, C
-            st = stats[-1]
-            C = cur_k
-            if pool:
-                G = R // pool
-                out = torch.empty(G, C, dtype=torch.bfloat16, device=dev)
-                arg = torch.empty(G, C, dtype=torch.uint8, device=dev)
-                _launch("pcb_bn_act_max_bf16", R * C, cur.data_ptr(), st[2].data_ptr(), st[3].data_ptr(), G, pool,
-                        C, act, out.data_ptr(), arg.data_ptr())
-            else:
-                arg = None
-                out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-                _launch("pcb_bn_act_bf16", R * C, cur.data_ptr(), st[2].data_ptr(), st[3].data_ptr(), R, C, act,
-                        out.data_ptr())
-        ctx.save_for_backward(x, arg, stz, *ys, *wts)
-        ctx.cfg = (act, pool, perm, L, [int(t[6]) for t in layers], [t[0].shape for t in layers],
-                   [t[1] is not None for t in layers], [t[2] is not None for t in layers], need_dx)
+            _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, x.data_ptr(), R, Kp, perm, act, pool, int(need_dx),
+                    wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
+                    0 if arg is None else arg.data_ptr())
+        ctx.save_for_backward(x, arg, ybuf, stz, wbuf, *[t[0] for t in layers])
+        ctx.cfg = (act, pool, perm, L, need_dx, [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
         return out
 
     @staticmethod
     def backward(ctx, g):
-        act, pool, perm, L, trainings, wshapes, has_bias, has_affine, had_wt0 = ctx.cfg
+        act, pool, perm, L, need_dx, flags = ctx.cfg
         saved = ctx.saved_tensors
-        x, arg, stz = saved[0], saved[1], saved[2]
-        ys, wts = saved[3:3 + L], saved[3 + L:3 + 2 * L]
-        widths = [ws[0] for ws in wshapes]
-        stats = _stat_views(stz, widths)
+        x, arg, ybuf, stz, wbuf = saved[:5]
+        weights = saved[5:5 + L]
+        widths = [w.shape[0] for w in weights]
         dev = x.device
-        R = x.shape[0]
+        R, Kp = x.shape
+        lib = _lib.load()
+        g = g.float().contiguous() if pool else g.to(torch.bfloat16).contiguous()
         grads = [None] * (L * _FusedStack.NPER)
-        dz = None  # dense upstream gradient of layer l's activation (bf16 rows)
+        outs = []
+        kp, ws_elems = Kp, 0
+        for l, w in enumerate(weights):
+            C = widths[l]
+            has_bias, has_affine, _ = flags[l]
+            base = l * _FusedStack.NPER
+            dw = grads[base + 0] = torch.empty_like(w) if ctx.needs_input_grad[5 + base] else None
+            dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev) if has_bias else None
+            dgamma = grads[base + 2] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
+            dbeta = grads[base + 3] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
+            outs.append((dw, dgamma, dbeta, dbias))
+            if dw is not None:
+                ws_elems = max(ws_elems, lib.pcb_gemm_tn_workspace(R, C, kp))
+            kp = C
+        layers = [(w, None, None, None, None, None, flags[l][2]) for l, w in enumerate(weights)]
+        desc = _stack_desc(layers, widths, ybuf, R, outs)
+        want_dx = bool(ctx.needs_input_grad[0]) and need_dx
+        dx = torch.empty(R, Kp, dtype=torch.bfloat16, device=dev) if want_dx else None
+        maxw = max([Kp] + widths[:-1])
+        dzbuf = torch.empty(2 * R * maxw, dtype=torch.bfloat16, device=dev) if L > 1 else None
+        parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            if pool:
-                dout = g.float().contiguous()
-            else:
-                dz = g.to(torch.bfloat16).contiguous()
-            lib = _lib.load()
-            red_parts = {}  # layer -> (partials, nparts) accumulated by the dgrad GEMM of the layer above
-            for l in range(L - 1, -1, -1):
-                y, st = ys[l], stats[l]
-                C = widths[l]
-                K = x.shape[1] if l == 0 else widths[l - 1]
-                training = trainings[l]
-                pooled = pool and l == L - 1
-                scale, shift, mean, invstd, bsums, p, q = st[2], st[3], st[4], st[5], st[6:8], st[8], st[9]
-                if l in red_parts:
-                    parts, nparts = red_parts[l]
-                    sums_ptr = parts.data_ptr()
-                else:
-                    nparts, sums_ptr = 1, bsums.data_ptr()
-                    if pooled:
-                        _launch("pcb_bn_act_max_bwd_reduce_bf16", R * C, dout.data_ptr(), arg.data_ptr(), y.data_ptr(),
-                                scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R // pool, pool,
-                                C, act, bsums.data_ptr())
-                    else:
-                        _launch("pcb_bn_act_bwd_reduce_bf16", R * C, dz.data_ptr(), y.data_ptr(), scale.data_ptr(),
-                                shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R, C, act, bsums.data_ptr())
-                # p, q of dy(dz, y) and, straight into fresh tensors, the BatchNorm/bias gradients
-                base = l * _FusedStack.NPER
-                dgamma = dbeta = dbias = None
-                if has_affine[l]:
-                    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-                    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-                    grads[base + 2], grads[base + 3] = dgamma, dbeta
-                if has_bias[l]:
-                    dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev)
-                _launch("pcb_bn_bwd_finalize", C, sums_ptr, nparts, R, C, scale.data_ptr(), mean.data_ptr(),
-                        invstd.data_ptr(), training, p.data_ptr(), q.data_ptr(),
-                        0 if dgamma is None else dgamma.data_ptr(), 0 if dbeta is None else dbeta.data_ptr(),
-                        0 if dbias is None else dbias.data_ptr())
-                apro = 3 if pooled else 2
-                a0 = 0 if pooled else dz.data_ptr()
-                dptr = dout.data_ptr() if pooled else 0
-                aptr = arg.data_ptr() if pooled else 0
-                nbytes = (2 * R * C + 5 * (R // pool) * C if pooled else 4 * R * C) + 2 * R * K
-                # weight gradient: dW = dy^T . x_l, with x_l = act(BN(y_{l-1})) recomputed on load;
-                # written in the parameter's own [Cout, Cin] layout (padding dropped by the reduce)
-                k = wshapes[l][1]
-                dw = grads[base + 0] = torch.empty(wshapes[l], dtype=torch.float32, device=dev)
-                ws = torch.empty(lib.pcb_gemm_tn_workspace(R, C, K), dtype=torch.float32, device=dev)
-                if l:
-                    ps = stats[l - 1]
-                    _launch("pcb_gemm_tn_bf16", nbytes, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                            p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, 1,
-                            ys[l - 1].data_ptr(), ps[2].data_ptr(), ps[3].data_ptr(), act, R, C, K, ws.data_ptr(),
-                            dw.data_ptr(), k, 0)
-                else:
-                    _launch("pcb_gemm_tn_bf16", nbytes, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                            p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, 0, x.data_ptr(), 0, 0,
-                            0, R, C, K, ws.data_ptr(), dw.data_ptr(), k, perm)
-                # input gradient: dz_{l-1} = dy . W   (skipped for the first layer if x needs none)
-                if l or (ctx.needs_input_grad[0] and had_wt0):
-                    wt = wts[l]  # [K, C]: row n = input column, contiguous over C
-                    dprev = torch.empty(R, K, dtype=torch.bfloat16, device=dev)
-                    if l and K <= 128:
-                        # ... and, in its epilogue, the BatchNorm-backward sums of layer l-1
-                        ps = stats[l - 1]
-                        npr = lib.pcb_gemm_nt_partials(apro, R, K)
-                        parts = torch.empty(npr, 2, K, dtype=torch.float32, device=dev)
-                        _launch("pcb_gemm_nt_red_bf16", nbytes + 2 * R * K, apro, a0, y.data_ptr(), scale.data_ptr(),
-                                shift.data_ptr(), p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act,
-                                wt.data_ptr(), R, K, C, dprev.data_ptr(), ys[l - 1].data_ptr(), ps[2].data_ptr(),
-                                ps[3].data_ptr(), ps[4].data_ptr(), ps[5].data_ptr(), act, parts.data_ptr())
-                        red_parts[l - 1] = (parts, npr)
-                    else:
-                        _launch("pcb_gemm_nt_bf16", nbytes, apro, a0, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                p.data_ptr(), q.data_ptr(), dptr, aptr, pool if pooled else 1, act, wt.data_ptr(), R, K, C,
-                                dprev.data_ptr(), 0)
-                else:
-                    dprev = None
-                dz = dprev
-        return (dz, None, None, None, None, *grads)
+            _launch("pcb_mlp_stack_backward", 0, L, desc, x.data_ptr(), g.data_ptr(),
+                    0 if arg is None else arg.data_ptr(), R, Kp, perm, act, pool, int(need_dx), wbuf.data_ptr(),
+                    stz.data_ptr(), parts.data_ptr(), ws.data_ptr(), 0 if dzbuf is None else dzbuf.data_ptr(),
+                    0 if dx is None else dx.data_ptr())
+        return (dx, None, None, None, None, *grads)
 
 
-def _stat_views(stz, widths):
-    """Per-layer [10, C] views of a stack's flat constants buffer."""
-    out, off = [], 0
-    for c in widths:
-        out.append(stz[off:off + 10 * c].view(10, c))
-        off += 10 * c
-    return out
+_MAX_PARTS = 768  # upper bound of pcb_gemm_nt_partials (persistent workgroups of a gemm_nt launch)
 
 
-def _prep_weights(weights, k0p, perm, need_wt0, dev):
-    """bf16 GEMM operands of a stack's layers from the fp32 master weights, in one launch
-    (pcb_prep_weights_bf16): wp_l [C_l, Kp_l] in the column layout of the layer's input rows
-    (perm applies to layer 0, whose rows are k0p wide) and wt_l = wp_l^T for the input-gradient
-    GEMM (layer 0's only if need_wt0).  Returns (wps, wts); a missing wt is an empty tensor."""
-    import ctypes
-    n = len(weights)
-    dims, total = [], 0
-    kp = k0p
-    for l, w in enumerate(weights):
-        c = w.shape[0]
-        k = w.numel() // c
-        want_t = l > 0 or need_wt0
-        dims.append((c, k, kp, perm if l == 0 else 0, total, want_t))
-        total += c * kp * (2 if want_t else 1)
-        kp = c
-    buf = torch.empty(total, dtype=torch.bfloat16, device=dev)
-    base = buf.data_ptr()
-    wps, wts, desc = [], [], []
-    for w, (c, k, kp, pm, off, want_t) in zip(weights, dims):
+def _stack_desc(layers, widths, ybuf, R, outs=None):
+    """Host descriptor table of pcb_mlp_stack_forward/backward: 16 int64 per layer (pcb_hip.h)."""
+    vals, yoff = [], 0
+    ybase = ybuf.data_ptr()
+    for l, t in enumerate(layers):
+        w, bias, gamma, beta, rm, rv, training = t[:7]
         if not (w.is_contiguous() and w.dtype == torch.float32):
             raise TypeError("fused bf16 layers expect contiguous fp32 master weights")
-        wps.append(buf[off:off + c * kp].view(c, kp))
-        wts.append(buf[off + c * kp:off + 2 * c * kp].view(kp, c) if want_t else buf[0:0])
-        desc += [w.data_ptr(), base + 2 * off, (base + 2 * (off + c * kp)) if want_t else 0, c, k, kp, pm, 0]
-    for i in range(0, n, 8):
-        m = min(8, n - i)
-        arr = (ctypes.c_longlong * (8 * m))(*desc[8 * i:8 * (i + m)])
-        _launch("pcb_prep_weights_bf16", total, m, arr)
-    return wps, wts
+        C = widths[l]
+        o = outs[l] if outs is not None else (None, None, None, None)
+        vals += [w.data_ptr(),
+                 0 if bias is None else bias.data_ptr(), 0 if gamma is None else gamma.data_ptr(),
+                 0 if beta is None else beta.data_ptr(), 0 if rm is None else rm.data_ptr(),
+                 0 if rv is None else rv.data_ptr(), C, w.numel() // C, int(bool(training)), ybase + 2 * yoff,
+                 0 if o[0] is None else o[0].data_ptr(), 0 if o[1] is None else o[1].data_ptr(),
+                 0 if o[2] is None else o[2].data_ptr(), 0 if o[3] is None else o[3].data_ptr(), 0, 0]
+        yoff += R * C
+    return (ctypes.c_longlong * len(vals))(*vals)
 
 
 def _stack_fusable(convs, bns):
