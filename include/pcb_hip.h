@@ -185,8 +185,12 @@ int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream
  * train-mode BatchNorm) added to the mean that enters running_mean.  training == 0: running
  * statistics, bias folded into shift.  gamma/beta/bias/running_* may be NULL where unused.
  * mean/invstd [C] are outputs for the backward pass.
+ * count: the number of samples the statistics stand for in the unbiased running-variance factor
+ * count/(count-1); 0 means rows.  (It exceeds rows when every row is a sample repeated count/rows
+ * times -- nearest-neighbour upsampling before the layer, models/model.py:164 -- whose mean and
+ * biased variance equal those of the distinct rows.)
  */
-int pcb_bn_finalize(const float *sums, int nparts, long rows, int C, const float *gamma, const float *beta,
+int pcb_bn_finalize(const float *sums, int nparts, long rows, long count, int C, const float *gamma, const float *beta,
                     const float *bias, float *running_mean, float *running_var, float momentum,
                     float eps, int training, float *scale, float *shift, float *mean, float *invstd,
                     void *stream);
@@ -355,7 +359,8 @@ int pcb_interpolate_bwd_csr_bf16(const void *grad_rows, int ld, int col0, const 
  *   [8] 1: batch statistics (training), 0: running statistics
  *   [9] y bf16 [R,C]: the layer's pre-BatchNorm GEMM output (written by forward, read by backward)
  *   [10] dW fp32 [C,k]  [11] dgamma [C]  [12] dbeta [C]  [13] dbias [C]   (backward outputs, any may be 0)
- * fdesc: L x 2 doubles: momentum, eps.
+ * fdesc: L x 2 doubles: momentum, eps.  stat_repeat >= 1: every row of x stands for that many
+ * identical samples (see pcb_bn_finalize `count`); 1 otherwise.
  * x bf16 [R,Kp] rows in the column layout `perm` (see pcb_prep_weights_bf16); act 0/1/2;
  * pool = 0 (out bf16 [R,C_last]) or ns (out bf16 [R/ns,C_last] + argmax uint8).
  * Caller-owned scratch shared by forward and backward of the same stack:
@@ -368,7 +373,7 @@ int pcb_interpolate_bwd_csr_bf16(const void *grad_rows, int ld, int col0, const 
 #define PCB_STACK_MAX_LAYERS 16
 long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, int need_wt0);
 int pcb_mlp_stack_forward(int L, const long long *desc, const double *fdesc, const void *x, long R, int Kp,
-                          int perm, int act, int pool, int need_wt0, void *wbuf, float *stz, float *parts,
+                          int perm, int act, int pool, int need_wt0, int stat_repeat, void *wbuf, float *stz, float *parts,
                           void *out, unsigned char *argmax, void *stream);
 int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const void *g,
                            const unsigned char *argmax, long R, int Kp, int perm, int act, int pool,

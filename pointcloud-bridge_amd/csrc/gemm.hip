@@ -849,7 +849,7 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
             else
                 hipLaunchKernelGGL((gemm_nt_ares_kernel<PRO_DY_POOL, 32>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out);
         }
-        pcb_timer_end(st, timed, bytes);
+        pcb_timer_end(st, timed, bytes, pro, R, N, K);
         return pcb_check_launch();
     }
     switch (pro) {
@@ -858,7 +858,7 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
         case PRO_DY: launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
         default: launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
     }
-    pcb_timer_end(st, timed, bytes);
+    pcb_timer_end(st, timed, bytes, pro, R, N, K);
     return pcb_check_launch();
 }
 
@@ -991,6 +991,6 @@ extern "C" int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, con
         launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, st, &red);
     else
         launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, st, &red);
-    pcb_timer_end(st, timed, nt_bytes(pro, R, N, K, ns) + 2.0 * R * N);
+    pcb_timer_end(st, timed, nt_bytes(pro, R, N, K, ns) + 2.0 * R * N, pro + 10, R, N, K);
     return pcb_check_launch();
 }

@@ -84,7 +84,7 @@ __device__ __forceinline__ int clamp_index(int64_t j, int n)
 
 // roofline timer hooks (stack.hip): no-ops unless pcb_timer_start armed the timer
 void pcb_timer_begin(hipStream_t st, hipEvent_t *stop);
-void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes);
+void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes, int pro, long R, int N, int K);
 
 static inline int pcb_check_launch()
 {

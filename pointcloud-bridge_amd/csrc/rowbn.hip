@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restr
 // Block = 32 channels x 32 slab-lanes: the partial slabs are added by 32 lanes per channel
 // (coalesced 128-byte reads across the channels), combined through LDS in a fixed order.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
-    const float *__restrict__ sums, int nparts, long rows, int C, const float *__restrict__ gamma,
+    const float *__restrict__ sums, int nparts, long rows, long count, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ bias, float *__restrict__ running_mean,
     float *__restrict__ running_var, float momentum, float eps, int training, float *__restrict__ scale,
     float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out)
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
         var = var < 0.0f ? 0.0f : var;
         invstd = rsqrtf(var + eps);
         if (running_mean) {
-            const float unb = rows > 1 ? var * (n / (n - 1.0f)) : var;
+            const float m = (float)count;
+            const float unb = count > 1 ? var * (m / (m - 1.0f)) : var;
             running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (mean_y + b);
             running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unb;
         }
@@ -428,7 +429,7 @@ extern "C" int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, v
     return pcb_check_launch();
 }
 
-extern "C" int pcb_bn_finalize(const float *sums, int nparts, long rows, int C, const float *gamma,
+extern "C" int pcb_bn_finalize(const float *sums, int nparts, long rows, long count, int C, const float *gamma,
                                const float *beta, const float *bias, float *running_mean,
                                float *running_var, float momentum, float eps, int training,
                                float *scale, float *shift, float *mean, float *invstd, void *stream)
@@ -436,7 +437,7 @@ extern "C" int pcb_bn_finalize(const float *sums, int nparts, long rows, int C, 
     if (!scale || !shift || !mean || !invstd || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
     if (training ? (!sums || nparts < 1) : (!running_mean || !running_var)) return PCB_ERR_INVALID_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, nparts,
-                       rows, C, gamma, beta, bias, running_mean, running_var, momentum, eps, training,
+                       rows, count > 0 ? count : rows, C, gamma, beta, bias, running_mean, running_var, momentum, eps, training,
                        scale, shift, mean, invstd);
     return pcb_check_launch();
 }

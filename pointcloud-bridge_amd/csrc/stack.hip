@@ -13,6 +13,9 @@
 // No device code here: everything goes through the entry points of gemm.hip / rowbn.hip.
 #include <hip/hip_runtime.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -27,6 +30,8 @@ struct Timer {
     bool on = false;       // sampling enabled right now
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> pool;
+    struct Rec { double bytes; int pro; long R; int N, K; };
+    std::vector<Rec> each;  // the timed launches (PCB_TIMER_VERBOSE listing)
     double bytes = 0.0;
     hipEvent_t get()
     {
@@ -55,12 +60,13 @@ void pcb_timer_begin(hipStream_t st, hipEvent_t *stop)
     *stop = b;
 }
 
-void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes)
+void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes, int pro, long R, int N, int K)
 {
     if (!stop) return;
     (void)hipEventRecord(stop, st);
     std::lock_guard<std::mutex> lk(g_timer.mu);
     g_timer.bytes += bytes;
+    g_timer.each.push_back({bytes, pro, R, N, K});
 }
 
 extern "C" int pcb_timer_start(void)
@@ -71,6 +77,7 @@ extern "C" int pcb_timer_start(void)
         g_timer.pool.push_back(p.second);
     }
     g_timer.events.clear();
+    g_timer.each.clear();
     g_timer.bytes = 0.0;
     g_timer.armed = true;
     g_timer.on = true;
@@ -91,12 +98,19 @@ extern "C" int pcb_timer_stop(long *launches, double *milliseconds, double *byte
     g_timer.armed = false;
     double ms = 0.0;
     long n = 0;
+    const bool verbose = getenv("PCB_TIMER_VERBOSE") != nullptr;
+    size_t i = 0;
     for (auto &p : g_timer.events) {
         float t = 0.0f;
         if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) {
             ms += t;
             ++n;
+            if (verbose && i < g_timer.each.size())
+                fprintf(stderr, "[pcb_timer] %zu pro=%d R=%ld N=%d K=%d: %.1f MB in %.1f us = %.2f TB/s\n", i,
+                        g_timer.each[i].pro, g_timer.each[i].R, g_timer.each[i].N, g_timer.each[i].K,
+                        g_timer.each[i].bytes / 1e6, t * 1e3, g_timer.each[i].bytes / (t * 1e-3) / 1e12);
         }
+        ++i;
         g_timer.pool.push_back(p.first);
         g_timer.pool.push_back(p.second);
     }
@@ -189,7 +203,8 @@ extern "C" long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, i
 }
 
 extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double *fdesc, const void *x, long R,
-                                     int Kp, int perm, int act, int pool, int need_wt0, void *wbuf, float *stz,
+                                     int Kp, int perm, int act, int pool, int need_wt0, int stat_repeat, void *wbuf,
+                                     float *stz,
                                      float *parts, void *out, unsigned char *argmax, void *stream)
 {
     Layer ly[PCB_STACK_MAX_LAYERS];
@@ -231,7 +246,7 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
         PCB_TRY(pcb_gemm_nt_bf16(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0, act,
                                  wb + a.wp_off, R, a.C, a.kp, a.y, stats ? parts : nullptr, stream));
         const int nparts = pcb_gemm_nt_partials(l ? 1 : 0, R, a.C);
-        PCB_TRY(pcb_bn_finalize(stats ? parts : nullptr, nparts, R, a.C, a.gamma, a.beta, a.bias, a.rmean, a.rvar,
+        PCB_TRY(pcb_bn_finalize(stats ? parts : nullptr, nparts, R, R * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma, a.beta, a.bias, a.rmean, a.rvar,
                                 (float)fdesc[2 * l], (float)fdesc[2 * l + 1], a.training, row(stz, a, 2),
                                 row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), stream));
         cur = a.y;

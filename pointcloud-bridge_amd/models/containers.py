@@ -90,18 +90,40 @@ class MultiScaleFeatureFusion(nn.Module):
         for f, conv in zip(features_list, self.convs):
             B, _, S = f.shape
             rows = _channels_last(f)
-            if S != n:
-                r = n // S
-                if n % S == 0 and (r & (r - 1)) == 0:
-                    # scale = S/n = 2^-j is exact in fp32: nearest source of point i is i // r, i.e.
-                    # every coarse row repeated r times (its backward is a plain sum over r rows)
-                    rows = rows.unsqueeze(2).expand(B, S, r, rows.shape[2]).reshape(B, n, rows.shape[2])
-                else:
-                    ramp = torch.arange(S, dtype=torch.float32, device=f.device).view(1, 1, S)
-                    src = F.interpolate(ramp, size=n).view(n).long()  # the very index map F.interpolate uses
-                    rows = rows.index_select(1, src)
+            r = n // S
+            if S != n and n % S == 0 and (r & (r - 1)) == 0:
+                # scale = S/n = 2^-j is exact in fp32: nearest source of point i is i // r, i.e.
+                # every coarse row repeated r times (its backward is a plain sum over r rows)
+                if rowmlp.is_bf16() and isinstance(conv[1], nn.BatchNorm1d) and not isinstance(conv[1], nn.SyncBatchNorm):
+                    # A pointwise layer commutes with the repetition, and batch statistics over
+                    # rows repeated r times each equal those over the distinct rows: run the layer
+                    # on the S coarse rows (r times less GEMM work, forward and backward) and
+                    # repeat its output.  Only the sample count of the unbiased running variance
+                    # differs, which stat_repeat restores.
+                    o = rowmlp.conv_bn_act(conv[0], conv[1], rows.reshape(B * S, -1), rowmlp.ACT_RELU, stat_repeat=r)
+                    outs.append(o.view(B, S, 1, -1).expand(B, S, r, o.shape[1]))  # repeated on write below
+                    continue
+                rows = rows.unsqueeze(2).expand(B, S, r, rows.shape[2]).reshape(B, n, rows.shape[2])
+            elif S != n:
+                ramp = torch.arange(S, dtype=torch.float32, device=f.device).view(1, 1, S)
+                src = F.interpolate(ramp, size=n).view(n).long()  # the very index map F.interpolate uses
+                rows = rows.index_select(1, src)
             outs.append(_seq_rows(conv, rows.reshape(B * n, -1)).view(B, n, -1))
-        return torch.cat(outs, dim=2)
+        if all(o.dim() == 3 for o in outs):
+            return torch.cat(outs, dim=2)
+        # some levels are still [B,S,r,C] views of coarse rows: each is written once, broadcast over
+        # r, straight into its column block of the concatenated buffer
+        B = outs[0].shape[0]
+        fused = torch.empty(B, n, sum(o.shape[-1] for o in outs), dtype=outs[0].dtype, device=outs[0].device)
+        col = 0
+        for o in outs:
+            c = o.shape[-1]
+            if o.dim() == 4:
+                fused.view(B, o.shape[1], o.shape[2], -1)[..., col:col + c] = o
+            else:
+                fused[..., col:col + c] = o
+            col += c
+        return fused
 
 
 class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):

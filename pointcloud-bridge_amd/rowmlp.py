@@ -133,7 +133,7 @@ class _LinearBNAct(torch.autograd.Function):
         with torch.cuda.device(dev):
             if training:
                 _launch("pcb_colstats_bf16", R * C, y.data_ptr(), R, C, sums.data_ptr())
-            _launch("pcb_bn_finalize", C, sums.data_ptr(), 1, R, C,
+            _launch("pcb_bn_finalize", C, sums.data_ptr(), 1, R, 0, C,
                     0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
                     0 if bias is None else bias.data_ptr(),
                     0 if running_mean is None else running_mean.data_ptr(),
@@ -246,13 +246,13 @@ class _FusedStack(torch.autograd.Function):
     only y_l = x_l W_l^T is stored.  The last layer's activation is materialised (rows) or
     max-pooled over `pool` consecutive rows.
 
-    Flat argument list: x, act, pool, perm, L, then per layer
+    Flat argument list: x, act, pool, perm, stat_repeat, L, then per layer
     (weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps)."""
 
     NPER = 9
 
     @staticmethod
-    def forward(ctx, x, act, pool, perm, L, *flat):
+    def forward(ctx, x, act, pool, perm, stat_repeat, L, *flat):
         dev = x.device
         R, Kp = x.shape
         layers = [flat[i * _FusedStack.NPER:(i + 1) * _FusedStack.NPER] for i in range(L)]
@@ -275,7 +275,7 @@ class _FusedStack(torch.autograd.Function):
             arg = None
         with torch.cuda.device(dev):
             _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, x.data_ptr(), R, Kp, perm, act, pool, int(need_dx),
-                    wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
+                    int(stat_repeat), wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
                     0 if arg is None else arg.data_ptr())
         ctx.save_for_backward(x, arg, ybuf, stz, wbuf, *[t[0] for t in layers])
         ctx.cfg = (act, pool, perm, L, need_dx, [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
@@ -299,7 +299,7 @@ class _FusedStack(torch.autograd.Function):
             C = widths[l]
             has_bias, has_affine, _ = flags[l]
             base = l * _FusedStack.NPER
-            dw = grads[base + 0] = torch.empty_like(w) if ctx.needs_input_grad[5 + base] else None
+            dw = grads[base + 0] = torch.empty_like(w) if ctx.needs_input_grad[6 + base] else None
             dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev) if has_bias else None
             dgamma = grads[base + 2] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
             dbeta = grads[base + 3] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
@@ -320,7 +320,7 @@ class _FusedStack(torch.autograd.Function):
                     0 if arg is None else arg.data_ptr(), R, Kp, perm, act, pool, int(need_dx), wbuf.data_ptr(),
                     stz.data_ptr(), parts.data_ptr(), ws.data_ptr(), 0 if dzbuf is None else dzbuf.data_ptr(),
                     0 if dx is None else dx.data_ptr())
-        return (dx, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, *grads)
 
 
 _MAX_PARTS = 768  # upper bound of pcb_gemm_nt_partials (persistent workgroups of a gemm_nt launch)
@@ -350,7 +350,7 @@ def _stack_fusable(convs, bns):
     return all(c.out_channels % 8 == 0 and not isinstance(b, nn.SyncBatchNorm) for c, b in zip(convs, bns))
 
 
-def _fused_stack(convs, bns, x, act, pool, perm):
+def _fused_stack(convs, bns, x, act, pool, perm, stat_repeat=1):
     kp = x.shape[1] if perm != 0 else pad8(convs[0].in_channels)
     xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
     flat = []
@@ -369,17 +369,19 @@ def _fused_stack(convs, bns, x, act, pool, perm):
                  bn.running_mean if (track or not training) else None,
                  bn.running_var if (track or not training) else None,
                  training, momentum, bn.eps]
-    return _FusedStack.apply(xr, act, pool, perm, len(convs), *flat)
+    return _FusedStack.apply(xr, act, pool, perm, stat_repeat, len(convs), *flat)
 
 
 # ---------------------------------------------------------------------------------------------
 # public helpers used by the modules
 # ---------------------------------------------------------------------------------------------
-def conv_bn_act(conv, bn, x, act=ACT_RELU, pool=0, perm=0):
+def conv_bn_act(conv, bn, x, act=ACT_RELU, pool=0, perm=0, stat_repeat=1):
     """act(bn(conv(x))) on rows x [R, K]; with pool = ns also the max over each ns consecutive rows.
 
     perm = C > 0: x was written by pcb_group_rows_bf16 (C feature columns first, then the 3 centred
-    coordinates); bf16 mode only.  Returns [R, Cout] or [R/pool, Cout] in the mode's dtype."""
+    coordinates); bf16 mode only.  stat_repeat = r > 1 (bf16 fused engine only): every row stands
+    for r identical samples, which only matters for the unbiased running-variance factor.
+    Returns [R, Cout] or [R/pool, Cout] in the mode's dtype."""
     if not is_bf16():
         y = _act_torch(_bn_rows_fp32(bn, F.linear(x, _weight2d(conv), conv.bias)), act)
         if pool:
@@ -396,7 +398,9 @@ def conv_bn_act(conv, bn, x, act=ACT_RELU, pool=0, perm=0):
             y = y.view(-1, pool, y.shape[1]).max(dim=1)[0]
         return y
     if _ENGINE == "fused":
-        return _fused_stack([conv], [bn], x, act, pool, perm)
+        return _fused_stack([conv], [bn], x, act, pool, perm, stat_repeat)
+    if stat_repeat != 1:
+        raise NotImplementedError("stat_repeat needs the fused engine")
     kp = x.shape[1] if perm != 0 else pad8(conv.in_channels)
     xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
     momentum = _bn_bookkeeping(bn)
