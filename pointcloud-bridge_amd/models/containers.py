@@ -111,19 +111,43 @@ class MultiScaleFeatureFusion(nn.Module):
             outs.append(_seq_rows(conv, rows.reshape(B * n, -1)).view(B, n, -1))
         if all(o.dim() == 3 for o in outs):
             return torch.cat(outs, dim=2)
-        # some levels are still [B,S,r,C] views of coarse rows: each is written once, broadcast over
-        # r, straight into its column block of the concatenated buffer
-        B = outs[0].shape[0]
-        fused = torch.empty(B, n, sum(o.shape[-1] for o in outs), dtype=outs[0].dtype, device=outs[0].device)
+        return _RepeatConcat.apply(n, *outs)
+
+
+class _RepeatConcat(torch.autograd.Function):
+    """cat along channels of levels given as [B,n,C] rows or as [B,S,r,C] views of coarse rows
+    repeated r = n/S times: each level is written once, broadcast over r, straight into its column
+    block of the [B,n,sum C] buffer; backward hands every level its block of the gradient, summed
+    over the r repeats (no full-size intermediate in either direction)."""
+
+    @staticmethod
+    def forward(ctx, n, *levels):
+        B = levels[0].shape[0]
+        fused = torch.empty(B, n, sum(o.shape[-1] for o in levels), dtype=levels[0].dtype, device=levels[0].device)
         col = 0
-        for o in outs:
+        for o in levels:
             c = o.shape[-1]
             if o.dim() == 4:
                 fused.view(B, o.shape[1], o.shape[2], -1)[..., col:col + c] = o
             else:
                 fused[..., col:col + c] = o
             col += c
+        ctx.shapes = [tuple(o.shape) for o in levels]
         return fused
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, col = [], 0
+        B = g.shape[0]
+        for shp in ctx.shapes:
+            c = shp[-1]
+            if len(shp) == 4:
+                # the level was an expand() of [B,S,1,C]: autograd sums a [B,S,r,C] gradient over r
+                grads.append(g.view(B, shp[1], shp[2], -1)[..., col:col + c])
+            else:
+                grads.append(g[..., col:col + c])
+            col += c
+        return (None, *grads)
 
 
 class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):
