@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcb_hip.so")
+LIB_PATH = os.environ.get("PCB_LIB") or os.path.join(_HERE, "libpcb_hip.so")  # PCB_LIB: A/B builds
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

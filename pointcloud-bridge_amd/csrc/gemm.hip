@@ -34,6 +34,7 @@ typedef unsigned short u16;
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((uint32_t)h << 16); }
@@ -276,15 +277,22 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
             const long ntile = last_k ? tile + gridDim.x : tile;
             const int nk = last_k ? 0 : k0 + NT_BK;
             if (ntile < tiles_m) fetch(ntile, nk);
+            // operand fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run
+            bf16x8 fa[2], fb[2][4];
+            auto frags = [&](int buf, int ks) {
+                const int kk = ks * 16 + (lane >> 5) * 8;
+                fa[buf] = *reinterpret_cast<const bf16x8 *>(&As[(wave * 32 + (lane & 31)) * NT_LD + kk]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    fb[buf][j] = *reinterpret_cast<const bf16x8 *>(&Bs[(j * 32 + (lane & 31)) * NT_LD + kk]);
+            };
+            frags(0, 0);
 #pragma unroll
             for (int ks = 0; ks < NT_BK / 16; ++ks) {
-                const int kk = ks * 16 + (lane >> 5) * 8;
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[(wave * 32 + (lane & 31)) * NT_LD + kk]);
+                if (ks + 1 < NT_BK / 16) frags((ks + 1) & 1, ks + 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(j * 32 + (lane & 31)) * NT_LD + kk]);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fb[ks & 1][j], acc[j], 0, 0, 0);
             }
             __syncthreads();
         }
@@ -295,6 +303,9 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
         // two-byte ones.
         const long m0 = tile * NT_BM;
         u16 *const stage = smem + wave * (32 * NT_OUT_LD);
+        const long rows_here = R - m0 < NT_BM ? R - m0 : NT_BM;
+        const __amdgpu_buffer_rsrc_t orsrc =
+            __builtin_amdgcn_make_buffer_rsrc(out + m0 * N, 0, (int)(rows_here * N * 2), 0x00020000);
         // RED: the y rows of this tile are requested BEFORE the tile is stored.  (A load issued after
         // a store has to wait for the store's acknowledgement too -- the memory counter is shared --
         // and eight such round trips per tile cost more than the GEMM.)  Unconditional, from clamped
@@ -340,7 +351,12 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
             const long r = m0 + wave * 32 + rr;
             const int n = n0 + cc;
             const uint4 o = *reinterpret_cast<const uint4 *>(&stage[rr * NT_OUT_LD + cc]);
-            if (r < R && n < N) *reinterpret_cast<uint4 *>(out + r * N + n) = o;
+            // Unconditional buffer store; lanes outside the matrix get an out-of-range offset, which
+            // the hardware drops.  A store under a branch would hide the number of stores in flight
+            // from the compiler, and the wait for the prefetched operands at the top of the next
+            // stage would become a wait for every store acknowledgement (vmcnt(0)).
+            const int off = (r < R && n < N) ? (int)(((long)(wave * 32 + rr) * N + n) * 2) : -1;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{o.x, o.y, o.z, o.w}, orsrc, off, 0, 0);
             if (RED) {
                 float dz[8], yv[8];
                 unpack8(o, dz);
@@ -518,11 +534,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ares_kernel(Operand A_arg, con
 
 // ---- gemm_tn (weight gradient) ----------------------------------------------------------------
 constexpr int TN_BM = 128, TN_BN = 128, TN_RS = 32;  // RS rows of the reduction per stage
+constexpr int TN_NCH = TN_RS / 16;                    // 16-byte chunks per thread, operand and stage
 constexpr int TN_LD = 128 + 32;                       // row stride 320 B: conflict-free tr reads
+
+// Workgroup id -> position in a logical order in which neighbours share an XCD.  The dispatcher
+// deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2; tiles that
+// read the same operand rows should therefore sit 8 ids apart, not next to each other.  This
+// lists XCD 0's workgroups first, then XCD 1's, ... (a bijection for any grid size).
+__device__ __forceinline__ unsigned xcd_logical(unsigned id, unsigned total)
+{
+    const unsigned xcd = id & 7u, slot = id >> 3;
+    const unsigned q = total >> 3, rem = total & 7u;
+    return xcd * q + (xcd < rem ? xcd : rem) + slot;
+}
 
 template <int APRO, int BPRO>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand B_arg, long R, int M, int N,
-                                                       long rows_per_split, float *__restrict__ part)
+                                                       long rows_per_split, float *__restrict__ part,
+                                                       int tiles_m, int tiles_n)
 {
     const Operand A = local_copy(A_arg);
     const Operand B = local_copy(B_arg);
@@ -534,9 +563,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 outputs each
-    const int m0 = blockIdx.x * TN_BM;
-    const int n0 = blockIdx.y * TN_BN;
-    const long r_begin = (long)blockIdx.z * rows_per_split;
+    // 1-D grid; the N tiles (then M tiles) of one row split are neighbours on one XCD, so the
+    // operand rows they share are fetched from HBM once and found in that XCD's L2 afterwards
+    const unsigned logical = xcd_logical(blockIdx.x, gridDim.x);
+    const int tile_n = logical % tiles_n;
+    const int tile_m = (logical / tiles_n) % tiles_m;
+    const int split = logical / (tiles_n * tiles_m);
+    const int m0 = tile_m * TN_BM;
+    const int n0 = tile_n * TN_BN;
+    const long r_begin = (long)split * rows_per_split;
     const long r_end = r_begin + rows_per_split < R ? r_begin + rows_per_split : R;
 
     f32x16 acc[2][2];
@@ -547,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-    // staging: 32 rows x 16 chunks of 8 columns per operand -> 2 chunks per thread and operand.
+    // staging: RS rows x 16 chunks of 8 columns per operand -> NCH chunks per thread and operand.
     // A thread's column chunk never changes, so its per-column constants stay in registers.
     const int chunk = t & 15;
     const int rrow = t >> 4;  // 0..15
@@ -555,11 +590,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     Consts<BPRO> kb;
     ka.load(A, m0 + chunk * 8, M);
     kb.load(B, n0 + chunk * 8, N);
-    Raw<APRO> ra[2];
-    Raw<BPRO> rb[2];
+    Raw<APRO> ra[TN_NCH];
+    Raw<BPRO> rb[TN_NCH];
     auto fetch = [&](long r0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TN_NCH; ++i) {
             const long r = r0 + rrow + 16 * i;
             ra[i].load(A, r < r_end ? r : R, m0 + chunk * 8, R, M);
             rb[i].load(B, r < r_end ? r : R, n0 + chunk * 8, R, N);
@@ -574,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     if (r_begin < r_end) fetch(r_begin);
     for (long r0 = r_begin; r0 < r_end; r0 += TN_RS) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TN_NCH; ++i) {
             *reinterpret_cast<uint4 *>(&As[(rrow + 16 * i) * TN_LD + chunk * 8]) = ra[i].finish(ka, a_slope);
             *reinterpret_cast<uint4 *>(&Bs[(rrow + 16 * i) * TN_LD + chunk * 8]) = rb[i].finish(kb, b_slope);
         }
@@ -614,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
                 const int m = m0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 // one plain store per element into this split's slab (summed by reduce_slabs_kernel):
                 // thousands of workgroups adding into one small dW would serialise on its few lines
-                if (m < M && n < N) part[((long)blockIdx.z * M + m) * N + n] = acc[a][b][i];
+                if (m < M && n < N) part[((long)split * M + m) * N + n] = acc[a][b][i];
             }
         }
 }
@@ -728,7 +763,8 @@ long nt_grid_x(int pro, long R, int N)
 {
     const long tiles = (R + NT_BM - 1) / NT_BM;
     const long ny = (N + NT_BN - 1) / NT_BN;
-    const long chip = pro <= PRO_BNACT ? 768 : 512;
+    static const long fwd_chip = getenv("PCB_NT_FWD_GRID") ? atol(getenv("PCB_NT_FWD_GRID")) : 768;  // tuning knob
+    const long chip = pro <= PRO_BNACT ? fwd_chip : 512;
     const long resident = chip / ny > 0 ? chip / ny : 1;
     return tiles < resident ? tiles : resident;
 }
@@ -769,11 +805,12 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
 {
     long rps;
     const long splits = tn_splits(R, M, N, &rps);
-    const dim3 grid((M + TN_BM - 1) / TN_BM, (N + TN_BN - 1) / TN_BN, (unsigned)splits);
+    const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
+    const dim3 grid((unsigned)(tm * tn * splits));
     if (bpro == PRO_PLAIN)
-        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part);
+        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, tm, tn);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part);
+        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, tm, tn);
     const long elems = (long)M * N;
     long blocks = (elems + 63) / 64;
     if (blocks > 4096) blocks = 4096;
