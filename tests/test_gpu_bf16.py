@@ -236,7 +236,9 @@ def test_bf16_networks_track_fp32_networks(rm, name):
 
 def test_bf16_training_reaches_fp32_miou(rm):
     """Short training on a learnable synthetic task: mIoU (inference.py:814-855 definition) of the
-    bf16 mode within 5 points of the fp32 mode."""
+    bf16 mode within 7 points of the fp32 mode.  (Each mode alone varies by +-2.5 points from run to
+    run at this length -- fp32 atomics in the gather backward passes make training chaotic -- so the
+    bar is the spread of two such runs plus a margin, tools/miou_flake.py.)"""
     from pointcloud_bridge_amd import train
     from pointcloud_bridge_amd.models.containers import PointNet2
     enc = [(256, 0.2, 16, 6, [32, 32, 64]), (64, 0.4, 16, 67, [64, 64, 128]), (16, 0.8, 16, 131, [128, 128, 256])]
@@ -255,12 +257,12 @@ def test_bf16_training_reaches_fp32_miou(rm):
         rm.set_precision(mode)
         tr = train.Trainer(model, 5, lr=2e-3)
         torch.manual_seed(0)
-        for _ in range(60):
+        for _ in range(120):
             tr.train_step(data)
         miou[mode] = tr.evaluate([val])["miou"]
         rm.set_precision("fp32")
-    assert miou["fp32"] > 0.5, miou
-    assert abs(miou["bf16"] - miou["fp32"]) < 0.05, miou
+    assert miou["fp32"] > 0.6 and miou["bf16"] > 0.6, miou
+    assert abs(miou["bf16"] - miou["fp32"]) < 0.07, miou
 
 
 @pytest.mark.parametrize("D1,C,k", [(3, 64, 4), (0, 32, 3), (16, 256, 4), (5, 8, 3)])
@@ -291,3 +293,114 @@ def test_interpolate_concat_bf16_forward_backward(rm, D1, C, k):
     assert float(d.mean()) < 1e-2 * float(ref_feat.grad.abs().mean())
     if D1:
         assert torch.equal(skip.grad, gr[:, :D1])
+
+
+@pytest.mark.parametrize("perm,k,kp", [(0, 6, 8), (0, 64, 64), (3, 6, 8), (128, 131, 136), (-3, 259, 264), (-5, 13, 16)])
+def test_prep_weights_and_wgrad_layout_match_host_reference(rm, perm, k, kp):
+    """pcb_prep_weights_bf16 == padded_weight_from (+ transpose); pcb_gemm_tn_bf16's out_cols/out_perm
+    output == _unpad_weight_grad of the padded result (bitwise: same sums, other placement)."""
+    import ctypes
+    from pointcloud_bridge_amd import _lib
+    from pointcloud_bridge_amd.ops import _launch
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    C, R = 64, 4096
+    w = torch.randn(C, k, 1, 1, generator=g).to(dev)
+    ref = rm.padded_weight_from(w, kp, perm)
+    wp = torch.empty(C, kp, dtype=torch.bfloat16, device=dev)
+    wt = torch.empty(kp, C, dtype=torch.bfloat16, device=dev)
+    desc = (ctypes.c_longlong * 8)(w.data_ptr(), wp.data_ptr(), wt.data_ptr(), C, k, kp, perm, 0)
+    _launch("pcb_prep_weights_bf16", 0, 1, desc)
+    assert torch.equal(wp, ref) and torch.equal(wt, ref.t().contiguous())
+
+    dz = torch.randn(R, C, generator=g).to(dev).to(torch.bfloat16)
+    x = torch.randn(R, kp, generator=g).to(dev).to(torch.bfloat16)
+    lib = _lib.load()
+    ws = torch.empty(lib.pcb_gemm_tn_workspace(R, C, kp), dtype=torch.float32, device=dev)
+    full = torch.empty(C, kp, dtype=torch.float32, device=dev)
+    real = torch.full((C, k), float("nan"), dtype=torch.float32, device=dev)
+    for out, cols, pm in ((full, 0, 0), (real, k, perm)):
+        _launch("pcb_gemm_tn_bf16", 0, 0, dz.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(), 0, 0, 0, R, C, kp,
+                ws.data_ptr(), out.data_ptr(), cols, pm)
+    assert torch.equal(real, rm._unpad_weight_grad(full, k, perm).contiguous())
+    assert _close(full, dz.float().t() @ x.float(), 2e-3)
+
+
+def test_stack_call_equals_layer_by_layer_calls(rm):
+    """pcb_mlp_stack_forward/backward enqueue exactly the per-layer entry points: a 3-layer stack run
+    as ONE stack equals the same layers run as three 1-layer stacks chained through autograd, up to
+    the one extra bf16 rounding of the materialised activations between them."""
+    rm.set_precision("bf16")
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    widths, K, R, pool = [64, 64, 128], 8, 4096, 16
+    convs = nn.ModuleList(nn.Conv2d(a, b, 1) for a, b in zip([K] + widths[:-1], widths)).to(dev)
+    bns = nn.ModuleList(nn.BatchNorm2d(b) for b in widths).to(dev)
+    x = torch.randn(R, K, device=dev).to(torch.bfloat16).requires_grad_(True)
+
+    def run(fused):
+        for m in list(convs) + list(bns):
+            m.zero_grad(set_to_none=True)
+        for b in bns:
+            b.reset_running_stats()
+        x.grad = None
+        if fused:
+            out = rm.mlp_rows(convs, bns, x, pool=pool)
+        else:
+            h = x
+            for i, (c, b) in enumerate(zip(convs, bns)):
+                h = rm.conv_bn_act(c, b, h, pool=pool if i == len(convs) - 1 else 0)
+            out = h
+        out.float().square().sum().backward()
+        return (out.detach().float(), x.grad.float(), [c.weight.grad.clone() for c in convs],
+                [b.weight.grad.clone() for b in bns], [b.running_var.clone() for b in bns])
+
+    a, b = run(True), run(False)
+    assert _close(a[0], b[0], 1e-2) and _close(a[1], b[1], 3e-2)
+    for u, v in zip(a[2] + a[3], b[2] + b[3]):
+        assert _close(u, v, 3e-2)
+    for u, v in zip(a[4], b[4]):
+        assert torch.allclose(u, v, rtol=2e-2, atol=1e-4)
+    rm.set_precision("fp32")
+
+
+def test_fusion_on_coarse_rows_matches_full_resolution(rm):
+    """MultiScaleFeatureFusion in bf16 mode runs Conv+BN+ReLU on the coarse rows and repeats the
+    output; that must equal the reference order (F.interpolate to N points first, models/model.py:164)
+    computed by the same kernels (coarse_rows = False), including the running statistics, and stay
+    within bf16 distance of the fp32 mode."""
+    from pointcloud_bridge_amd.models.containers import MultiScaleFeatureFusion
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    B, n = 2, 512
+    levels = [(32, 64), (32, 128), (16, n)]
+    fus = MultiScaleFeatureFusion([c for c, _ in levels], 16).to(dev).train()
+    feats = [torch.randn(B, c, s, device=dev).to(torch.bfloat16).float() for c, s in levels]
+
+    def run(mode, coarse):
+        rm.set_precision(mode)
+        fus.coarse_rows = coarse
+        for conv in fus.convs:
+            conv[1].reset_running_stats()
+        fus.zero_grad(set_to_none=True)
+        xs = [f.clone().requires_grad_(True) for f in feats]
+        out = fus(xs)
+        (out.float() * torch.linspace(-1, 1, out.shape[-1], device=dev)).sum().backward()
+        return (out.detach().float(), [x.grad for x in xs], [c[0].weight.grad.clone() for c in fus.convs],
+                [c[1].running_var.clone() for c in fus.convs], [c[1].running_mean.clone() for c in fus.convs])
+
+    try:
+        fp32, full, got = run("fp32", True), run("bf16", False), run("bf16", True)
+    finally:
+        rm.set_precision("fp32")
+        fus.coarse_rows = True
+    assert got[0].shape == full[0].shape == (B, n, 48)
+    # same kernels, same rounding: only the summation order of the statistics differs
+    assert _close(got[0], full[0], 2e-3)
+    for u, v in zip(got[1] + got[2], full[1] + full[2]):
+        assert _close(u, v, 5e-3)
+    for u, v in zip(got[3] + got[4], full[3] + full[4]):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-6)   # the unbiased count is B*n in both
+    assert _close(got[0], fp32[0], 1e-2)
+    for u, v in zip(got[3] + got[4], fp32[3] + fp32[4]):
+        assert torch.allclose(u, v, rtol=5e-3, atol=2e-4)
