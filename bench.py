@@ -106,7 +106,8 @@ def main():
                          "the reference's own published metric (eva_model.py:137-168, model_performance_comparison.csv)")
     ap.add_argument("--graph", action="store_true",
                     help="train mode: replay forward+backward as one captured hipGraph instead of launching every "
-                         "kernel from the host (measured equal on MI355X: the step is GPU-bound, so off by default)")
+                         "kernel from the host (measured equal on MI355X: the step is GPU-bound, so off by default; "
+                         "pn2_msg / pn2_ssg only)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="pointwise-MLP arithmetic: bf16 activations (BASELINE config 2) or the fp32 parity mode")
     args = ap.parse_args()
@@ -132,6 +133,10 @@ def main():
         model = parallel.sync_batchnorm(model)
     parallel.broadcast_parameters(model)
     use_graph = args.mode == "train" and args.graph and args.precision == "bf16"
+    if use_graph and args.model == "dgcnn":
+        # replaying a captured DGCNN step ended in a GPU memory fault on MI355X (cause not found yet;
+        # the eager step is clean under the same tests) -- refuse rather than risk the device
+        raise SystemExit("--graph is supported for pn2_msg / pn2_ssg only")
     bucket = parallel.FlatGradAllReduce(model.parameters(), keep_grad_tensors=use_graph)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4,
                            fused=True)  # train_MulSca_PN2.py:125

@@ -25,5 +25,12 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_device_time_total", row_limit=70,
-                                                          max_name_column_width=42, max_shapes_column_width=70))
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    t = getattr(e, "self_device_time_total", 0)
+    if t > 0 and not e.key.startswith("void ") and "anonymous namespace" not in e.key and not e.key.startswith("Cijk"):
+        rows.append((t, e.count, e.key, str(e.input_shapes)[:110]))
+tot = sum(r[0] for r in rows)
+print(f"ops with GPU time: {tot/1e3:.2f} ms")
+for t, n, k, sh in sorted(rows, reverse=True)[:60]:
+    print(f"{t:9.1f} us {n:4d}x  {k:34s} {sh}")
