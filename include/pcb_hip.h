@@ -373,12 +373,37 @@ int pcb_interpolate_bwd_csr_bf16(const void *grad_rows, int ld, int col0, const 
 #define PCB_STACK_MAX_LAYERS 16
 long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, int need_wt0);
 int pcb_mlp_stack_forward(int L, const long long *desc, const double *fdesc, const void *x, long R, int Kp,
-                          int perm, int act, int pool, int need_wt0, int stat_repeat, void *wbuf, float *stz, float *parts,
-                          void *out, unsigned char *argmax, void *stream);
+                          int perm, int act, int pool, int need_wt0, int stat_repeat, const long long *gather,
+                          void *wbuf, float *stz, float *parts, void *out, unsigned char *argmax, void *stream);
 int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const void *g,
                            const unsigned char *argmax, long R, int Kp, int perm, int act, int pool,
-                           int need_wt0, const void *wbuf, float *stz, float *parts, float *workspace,
-                           void *dzbuf, void *dx, void *stream);
+                           int need_wt0, const long long *gather, const void *wbuf, float *stz, float *parts,
+                           float *workspace, void *dzbuf, void *dx, void *stream);
+
+/*
+ * First layer of a GROUPED stack evaluated per point and gathered (csrc/gatherlin.hip): a 1x1
+ * convolution of [x_j - c_s | f_j] (sample_and_group, models/pointnet2_utils.py:51-58) or
+ * [x_j - x_i | x_i] (get_graph_feature, models/DGCNN.py:90-107) equals u[idx(s,j)] + v[s] with the
+ * per-point products u (N rows per scene) and v (S rows per scene), both fp32 [.,C].
+ *   pcb_gather_add_bf16   y[r,:] = bf16(u[b*N + idx[r],:] + v[r/ns,:]), r over B*S*ns rows, and the
+ *                         column sums / sums of squares of y into [pcb_gather_add_partials(R,C)][2][C]
+ *                         slabs for pcb_bn_finalize.
+ *   pcb_scatter_dy_bf16   backward: dy = the layer's BatchNorm/activation backward built from
+ *                         (dz, y) or, pooled != 0, from (dout, argmax, y) of a max over the same ns
+ *                         rows, with scale/shift/p/q as in pcb_gemm_nt_bf16 pro 2/3;
+ *                         du[b*N + idx[r],:] += dy[r,:] (fp32 atomics, du zeroed by the caller),
+ *                         dv[r/ns,:] = sum over the group (overwritten).
+ * The stack calls take these through `gather` (NULL = ordinary stack): 8 int64 on the host,
+ *   {u | du, v | dv, idx, B, N, S, ns, 0}  (forward reads u, v; backward writes du, dv and zeroes du);
+ * layer 0 of desc then carries no weight (slots [0],[7],[10] unused) and x, Kp, perm, dx are ignored.
+ */
+int pcb_gather_add_partials(long R, int C);
+int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S, int ns, int C,
+                        void *y, float *sums, void *stream);
+int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *scale, const float *shift,
+                        const float *p, const float *q, const float *dout, const unsigned char *argmax, int act,
+                        const int64_t *idx, int B, int N, int S, int ns, int C, float *du, float *dv,
+                        void *stream);
 
 /*
  * HIP-event timing of the gemm_nt kernel family (pcb_gemm_nt_bf16 / pcb_gemm_nt_red_bf16, also when

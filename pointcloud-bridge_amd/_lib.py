@@ -47,8 +47,11 @@ SIGNATURES = {
     "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "pcb_prep_weights_bf16": [_i, _p, _p],
     "pcb_mlp_stack_wbuf_elems": [_i, _p, _i, _i],
-    "pcb_mlp_stack_forward": [_i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
-    "pcb_mlp_stack_backward": [_i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "pcb_mlp_stack_forward": [_i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "pcb_mlp_stack_backward": [_i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "pcb_gather_add_partials": [_l, _i],
+    "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_scatter_dy_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "pcb_timer_start": [],
     "pcb_timer_enable": [_i],
     "pcb_timer_stop": [_p, _p, _p],

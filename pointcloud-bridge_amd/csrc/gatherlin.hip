@@ -1,0 +1,213 @@
+// First layer of a grouped shared MLP evaluated per POINT and gathered, instead of per (centroid,
+// neighbour) ROW.
+//
+// The reference builds the grouped tensor and convolves it (models/pointnet2_utils.py:51-58 +
+// :149-151, :342-354;  models/DGCNN.py:90-107 + :134-136):
+//     SetAbstraction   row (s,j) = [x_j - c_s | f_j],   y = W [x_j - c_s ; f_j]
+//     EdgeConv         row (i,j) = [x_j - x_i | x_i],   y = W [x_j - x_i ; x_i]
+// A 1x1 convolution is linear, so  y(s,j) = u[idx(s,j)] + v[s]  with per-point products
+//     SA:        u = X Wx^T + F Wf^T  (N rows),   v = -C Wx^T        (S rows)
+//     EdgeConv:  u = X Wa^T           (N rows),   v = X (Wb - Wa)^T  (N rows)
+// i.e. the GEMM shrinks from S*ns rows to N + S rows (ns = 16..32 times fewer) and the grouped
+// tensor [S*ns, 3+C] is never written.  u, v are fp32 (the difference of two nearby points must
+// not be taken between bf16-rounded products); the caller computes them with ordinary GEMMs.
+//
+//   gather_add   y[r,:] = bf16(u[src(r),:] + v[r/ns,:])  + the BatchNorm statistics of y (slabs)
+//   scatter_dy   backward: dy[r,:] = BatchNorm/activation backward of the layer, built on the fly
+//                from (dz | dout+argmax, y) exactly as the GEMM prologues of gemm.hip do;
+//                du[src(r),:] += dy[r,:] (fp32 atomics; runs of equal src are combined first: ball
+//                query pads short groups by repeating one index), dv[s,:] = sum_j dy (no atomics).
+// The gradients of W, X, F, C follow from du, dv through the caller's small GEMMs.
+#include "pcb_common.h"
+
+namespace {
+
+typedef unsigned short u16;
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+__device__ __forceinline__ void unpack8(const uint4 &v, float *f)
+{
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ void load8(const float *p, float *f)
+{
+    const float4 a = *reinterpret_cast<const float4 *>(p);
+    const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+    f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+inline float slope_of(int act) { return act == 1 ? 0.0f : (act == 2 ? 0.2f : 1.0f); }
+
+// Lane t owns column chunk t % CT (8 columns) and walks rows t / CT, + RT, ... (CT = C/8 <= 256).
+__global__ __launch_bounds__(kThreads) void gather_add_kernel(const float *__restrict__ u,
+                                                               const float *__restrict__ v,
+                                                               const int64_t *__restrict__ idx, int N, int S,
+                                                               int ns, int C, long R, u16 *__restrict__ y,
+                                                               float *__restrict__ sums)
+{
+    __shared__ float red[kThreads * 16];
+    const int CT = C >> 3;
+    const int RT = kThreads / CT;
+    const int cc = threadIdx.x % CT;
+    const int rl = threadIdx.x / CT;
+    const long per_scene = (long)S * ns;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rl < RT) {
+        for (long r = (long)blockIdx.x * RT + rl; r < R; r += (long)gridDim.x * RT) {
+            const long b = r / per_scene;
+            const long src = b * N + clamp_index(idx[r], N);
+            float a[8], c[8];
+            load8(u + src * C + cc * 8, a);
+            load8(v + (r / ns) * C + cc * 8, c);
+            uint4 o;
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u16 lo = f2bf(a[2 * i] + c[2 * i]), hi = f2bf(a[2 * i + 1] + c[2 * i + 1]);
+                w[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+                const float f0 = bf2f(lo), f1 = bf2f(hi);  // statistics of the values the next kernels read
+                s[2 * i] += f0;
+                s[2 * i + 1] += f1;
+                q[2 * i] = fmaf(f0, f0, q[2 * i]);
+                q[2 * i + 1] = fmaf(f1, f1, q[2 * i + 1]);
+            }
+            o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+            *reinterpret_cast<uint4 *>(y + r * C + cc * 8) = o;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[threadIdx.x * 16 + i] = s[i];
+        red[threadIdx.x * 16 + 8 + i] = q[i];
+    }
+    __syncthreads();
+    // the workgroup's totals go to ITS slab (no atomics; pcb_bn_finalize adds the slabs in order)
+    for (int o = threadIdx.x; o < 2 * C; o += kThreads) {
+        const int m = o / C, c = o % C;
+        float a = 0.0f;
+        for (int r = 0; r < RT; ++r) a += red[(r * CT + (c >> 3)) * 16 + m * 8 + (c & 7)];
+        sums[((long)blockIdx.x * 2 + m) * C + c] = a;
+    }
+}
+
+// One lane per (centroid g, column chunk): walks the ns rows of the group.
+//   POOLED = 0: dz rows (bf16) given;  POOLED = 1: dout [G,C] fp32 + argmax [G,C] uint8 of a layer
+//   max-pooled over the same ns rows.
+template <int POOLED>
+__global__ __launch_bounds__(kThreads) void scatter_dy_kernel(
+    const u16 *__restrict__ dz, const u16 *__restrict__ y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ p, const float *__restrict__ q,
+    const float *__restrict__ dout, const unsigned char *__restrict__ arg, float slope,
+    const int64_t *__restrict__ idx, int N, int S, int ns, int C, long G, float *__restrict__ du,
+    float *__restrict__ dv)
+{
+    const int CT = C >> 3;
+    const long total = G * CT;
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+        const long g = e / CT;
+        const int c0 = (int)(e - g * CT) * 8;
+        const long b = g / S;
+        float sc[8], sh[8], pp[8], qq[8], d[8];
+        load8(scale + c0, sc);
+        load8(shift + c0, sh);
+        load8(p + c0, pp);
+        load8(q + c0, qq);
+        unsigned long long am = 0;
+        if (POOLED) {
+            load8(dout + g * C + c0, d);
+            am = *reinterpret_cast<const unsigned long long *>(arg + g * C + c0);
+        }
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dv: the whole group
+        float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // du: the current run of equal source indices
+        long run_src = -1;
+        for (int j = 0; j < ns; ++j) {
+            const long r = g * ns + j;
+            const long src = b * N + clamp_index(idx[r], N);
+            float yv[8], f[8];
+            unpack8(*reinterpret_cast<const uint4 *>(y + r * C + c0), yv);
+            if (POOLED) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = ((int)((am >> (8 * i)) & 0xff) == j) ? d[i] : 0.0f;
+            } else {
+                unpack8(*reinterpret_cast<const uint4 *>(dz + r * C + c0), f);
+            }
+            if (src != run_src) {
+                if (run_src >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) atomicAdd(&du[run_src * C + c0 + i], run[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) run[i] = 0.0f;
+                run_src = src;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float g1 = f[i] * (fmaf(yv[i], sc[i], sh[i]) > 0.0f ? 1.0f : slope);
+                const float dy = fmaf(sc[i], g1, fmaf(pp[i], yv[i], qq[i]));
+                run[i] += dy;
+                acc[i] += dy;
+            }
+        }
+        if (run_src >= 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) atomicAdd(&du[run_src * C + c0 + i], run[i]);
+        }
+        *reinterpret_cast<float4 *>(dv + g * C + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(dv + g * C + c0 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+inline long gather_add_grid(long R, int C)
+{
+    const int RT = kThreads / (C >> 3);
+    long blocks = (R + (long)RT * 8 - 1) / ((long)RT * 8);
+    return blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+}
+
+inline bool bad_c(int C) { return C <= 0 || (C & 7) != 0 || C > 2048; }
+
+}  // namespace
+
+extern "C" int pcb_gather_add_partials(long R, int C)
+{
+    if (R <= 0 || bad_c(C)) return 0;
+    return (int)gather_add_grid(R, C);
+}
+
+extern "C" int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S,
+                                   int ns, int C, void *y, float *sums, void *stream)
+{
+    if (!u || !v || !idx || !y || !sums || B <= 0 || N <= 0 || S <= 0 || ns <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
+    const long R = (long)B * S * ns;
+    hipLaunchKernelGGL(gather_add_kernel, dim3((unsigned)gather_add_grid(R, C)), dim3(kThreads), 0,
+                       (hipStream_t)stream, u, v, idx, N, S, ns, C, R, (u16 *)y, sums);
+    return pcb_check_launch();
+}
+
+extern "C" int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *scale,
+                                   const float *shift, const float *p, const float *q, const float *dout,
+                                   const unsigned char *argmax, int act, const int64_t *idx, int B, int N,
+                                   int S, int ns, int C, float *du, float *dv, void *stream)
+{
+    if (!y || !scale || !shift || !p || !q || !idx || !du || !dv || B <= 0 || N <= 0 || S <= 0 || ns <= 0)
+        return PCB_ERR_INVALID_ARG;
+    if (pooled ? (!dout || !argmax || ns > 255) : !dz) return PCB_ERR_INVALID_ARG;
+    if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
+    const long G = (long)B * S;
+    long blocks = (G * (C >> 3) + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (pooled)
+        hipLaunchKernelGGL(scatter_dy_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), 0, st, (const u16 *)dz,
+                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv);
+    else
+        hipLaunchKernelGGL(scatter_dy_kernel<0>, dim3((unsigned)blocks), dim3(kThreads), 0, st, (const u16 *)dz,
+                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv);
+    return pcb_check_launch();
+}

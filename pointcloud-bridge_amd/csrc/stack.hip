@@ -152,7 +152,7 @@ struct Layer {
 template <typename T>
 T *ptr(long long v) { return reinterpret_cast<T *>(static_cast<uintptr_t>(v)); }
 
-int parse(int L, const long long *desc, int Kp, int need_wt0, Layer *out)
+int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, Layer *out)
 {
     if (L < 1 || L > PCB_STACK_MAX_LAYERS || !desc) return PCB_ERR_INVALID_ARG;
     long woff = 0, soff = 0;
@@ -174,6 +174,17 @@ int parse(int L, const long long *desc, int Kp, int need_wt0, Layer *out)
         a.dgamma = ptr<float>(d[S_DGAMMA]);
         a.dbeta = ptr<float>(d[S_DBETA]);
         a.dbias = ptr<float>(d[S_DBIAS]);
+        if (gathered && l == 0) {
+            // layer 0 = gather_add of per-point products: no weights of its own in this call
+            if (!a.y || a.C <= 0 || (a.C & 7)) return PCB_ERR_INVALID_ARG;
+            a.kp = 0;
+            a.wp_off = woff;
+            a.wt_off = -1;
+            a.st_off = soff;
+            soff += 10L * a.C;
+            kp = a.C;
+            continue;
+        }
         if (!a.w || !a.y || a.C <= 0 || (a.C & 7) || a.k <= 0 || a.k > kp || (kp & 7)) return PCB_ERR_INVALID_ARG;
         a.kp = kp;
         a.wp_off = woff;
@@ -204,7 +215,7 @@ extern "C" long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, i
 {
     if (L < 1 || L > PCB_STACK_MAX_LAYERS || !desc) return 0;
     long total = 0;
-    int kp = Kp;
+    int kp = Kp;  // Kp == 0: layer 0 is a gathered layer and holds no weights here
     for (int l = 0; l < L; ++l) {
         const int C = (int)desc[(long)kSlots * l + S_C];
         total += (long)C * kp * ((l > 0 || need_wt0) ? 2 : 1);
@@ -213,14 +224,42 @@ extern "C" long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, i
     return total;
 }
 
+namespace {
+struct Gather {
+    float *u, *v;  // forward: u, v;  backward: du, dv
+    const int64_t *idx;
+    int B, N, S, ns;
+};
+bool parse_gather(const long long *g, Gather *out)
+{
+    if (!g) return false;
+    out->u = ptr<float>(g[0]);
+    out->v = ptr<float>(g[1]);
+    out->idx = ptr<const int64_t>(g[2]);
+    out->B = (int)g[3];
+    out->N = (int)g[4];
+    out->S = (int)g[5];
+    out->ns = (int)g[6];
+    return true;
+}
+}  // namespace
+
 extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double *fdesc, const void *x, long R,
-                                     int Kp, int perm, int act, int pool, int need_wt0, int stat_repeat, void *wbuf,
-                                     float *stz,
+                                     int Kp, int perm, int act, int pool, int need_wt0, int stat_repeat,
+                                     const long long *gather, void *wbuf, float *stz,
                                      float *parts, void *out, unsigned char *argmax, void *stream)
 {
     Layer ly[PCB_STACK_MAX_LAYERS];
-    PCB_TRY(parse(L, desc, Kp, need_wt0, ly));
-    if (!fdesc || !x || !wbuf || !stz || !out || R <= 0 || pool < 0 || (pool && (!argmax || R % pool))) return PCB_ERR_INVALID_ARG;
+    Gather ga;
+    const bool gathered = parse_gather(gather, &ga);
+    if (gathered) {
+        if (!ga.u || !ga.v || !ga.idx || (long)ga.B * ga.S * ga.ns != R || !parts) return PCB_ERR_INVALID_ARG;
+        Kp = 0;
+    }
+    PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, ly));
+    if (!fdesc || (!x && !gathered) || (!wbuf && !(gathered && L == 1)) || !stz || !out || R <= 0 || pool < 0 ||
+        (pool && (!argmax || R % pool)))
+        return PCB_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     unsigned short *wb = (unsigned short *)wbuf;
 
@@ -229,7 +268,7 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
     if (hipMemsetAsync(stz, 0, stz_floats * sizeof(float), st) != hipSuccess) return PCB_ERR_LAUNCH;
 
     // bf16 operands of all layers (chunks of 8 layers per launch)
-    for (int l0 = 0; l0 < L; l0 += 8) {
+    for (int l0 = gathered ? 1 : 0; l0 < L; l0 += 8) {
         const int n = L - l0 < 8 ? L - l0 : 8;
         long long pd[8 * 8];
         for (int i = 0; i < n; ++i) {
@@ -254,9 +293,15 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
         if (stats && !parts) return PCB_ERR_INVALID_ARG;
         const float *pscale = l ? row(stz, ly[l - 1], 2) : nullptr;
         const float *pshift = l ? row(stz, ly[l - 1], 3) : nullptr;
-        PCB_TRY(pcb_gemm_nt_bf16(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0, act,
-                                 wb + a.wp_off, R, a.C, a.kp, a.y, stats ? parts : nullptr, stream));
-        const int nparts = pcb_gemm_nt_partials(l ? 1 : 0, R, a.C);
+        int nparts;
+        if (gathered && l == 0) {
+            PCB_TRY(pcb_gather_add_bf16(ga.u, ga.v, ga.idx, ga.B, ga.N, ga.S, ga.ns, a.C, a.y, parts, stream));
+            nparts = pcb_gather_add_partials(R, a.C);
+        } else {
+            PCB_TRY(pcb_gemm_nt_bf16(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0,
+                                     act, wb + a.wp_off, R, a.C, a.kp, a.y, stats ? parts : nullptr, stream));
+            nparts = pcb_gemm_nt_partials(l ? 1 : 0, R, a.C);
+        }
         PCB_TRY(pcb_bn_finalize(stats ? parts : nullptr, nparts, R, R * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma, a.beta, a.bias, a.rmean, a.rvar,
                                 (float)fdesc[2 * l], (float)fdesc[2 * l + 1], a.training, row(stz, a, 2),
                                 row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), stream));
@@ -273,15 +318,23 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
 
 extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const void *g,
                                       const unsigned char *argmax, long R, int Kp, int perm, int act, int pool,
-                                      int need_wt0, const void *wbuf, float *stz, float *parts, float *workspace,
-                                      void *dzbuf, void *dx, void *stream)
+                                      int need_wt0, const long long *gather, const void *wbuf, float *stz,
+                                      float *parts, float *workspace, void *dzbuf, void *dx, void *stream)
 {
     Layer ly[PCB_STACK_MAX_LAYERS];
-    PCB_TRY(parse(L, desc, Kp, need_wt0, ly));
-    if (!x || !g || !wbuf || !stz || !workspace || R <= 0 || (pool && !argmax)) return PCB_ERR_INVALID_ARG;
+    Gather ga;
+    const bool gathered = parse_gather(gather, &ga);
+    if (gathered) {
+        if (!ga.u || !ga.v || !ga.idx || (long)ga.B * ga.S * ga.ns != R || dx) return PCB_ERR_INVALID_ARG;
+        Kp = 0;
+    }
+    PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, ly));
+    if ((!x && !gathered) || !g || (!wbuf && !(gathered && L == 1)) || !stz || (!workspace && !(gathered && L == 1)) ||
+        R <= 0 || (pool && !argmax))
+        return PCB_ERR_INVALID_ARG;
     if (dx && !need_wt0) return PCB_ERR_INVALID_ARG;
     const unsigned short *wb = (const unsigned short *)wbuf;
-    int maxw = Kp;
+    int maxw = Kp > 8 ? Kp : 8;
     for (int l = 0; l + 1 < L; ++l) maxw = ly[l].C > maxw ? ly[l].C : maxw;
     if (L > 1 && !dzbuf) return PCB_ERR_INVALID_ARG;
 
@@ -310,6 +363,15 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
         have_parts = false;
         const int apro = pooled ? 3 : 2;
         const int ns = pooled ? pool : 1;
+        if (gathered && l == 0) {
+            // gathered layer: its input gradients are du (per source point) and dv (per centroid)
+            if (pooled && pool != ga.ns) return PCB_ERR_INVALID_ARG;
+            if (hipMemsetAsync(ga.u, 0, sizeof(float) * (size_t)ga.B * ga.N * a.C, (hipStream_t)stream) != hipSuccess)
+                return PCB_ERR_LAUNCH;
+            PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx, ga.B,
+                                        ga.N, ga.S, ga.ns, a.C, ga.u, ga.v, stream));
+            break;
+        }
         // weight gradient, in the parameter's own layout
         if (a.dW) {
             if (l) {

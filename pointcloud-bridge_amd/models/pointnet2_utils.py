@@ -214,6 +214,29 @@ def _seq_rows(seq, x):
 # ---------------------------------------------------------------------------------------------
 # modules (reference: pointnet2_utils.py:115-360)
 # ---------------------------------------------------------------------------------------------
+def _grouped_mlp(convs, bns, xyz, new_xyz, feat, idx):
+    """Grouping + shared MLP + max over the neighbours of one set-abstraction scale
+    (reference :51-58 + :149-154 / :342-356) -> [B*S, C] rows.
+
+    bf16 mode with differentiable features of useful width: the first 1x1 conv is linear in
+    [x_j - c_s | f_j], so it is evaluated per point (u = X Wx^T + F Wf^T on N rows, v = -C Wx^T on S
+    rows, fp32) and the rows y0[s,j] = u[idx[s,j]] + v[s] are gathered (rowmlp.gathered_mlp): the
+    grouped tensor is never written and the first GEMM, its input gradient and the scatter of a
+    (3+C)-wide row gradient shrink to C0-wide gathers/scatters.  Otherwise rows are grouped first."""
+    B, S, ns = idx.shape
+    cf = 0 if feat is None else feat.shape[2]
+    if feat is not None and feat.requires_grad and cf >= 32 and rowmlp.gathered_ok(convs, bns):
+        N = xyz.shape[1]
+        w0 = convs[0].weight.view(convs[0].out_channels, 3 + cf)
+        wx, wf = w0[:, :3], w0[:, 3:]
+        u = torch.addmm(xyz.reshape(B * N, 3) @ wx.t(), feat.reshape(B * N, cf).float(), wf.t())
+        v = -(new_xyz.reshape(B * S, 3) @ wx.t())
+        return rowmlp.gathered_mlp(convs, bns, u, v, idx, pool=ns)
+    rows, perm = rowmlp.group_rows(xyz, new_xyz, feat, idx)
+    return rowmlp.mlp_rows(convs, bns, rows, pool=ns, perm=perm)
+
+
+
 class SetAbstraction(nn.Module):
     """Single-scale set abstraction (reference :115-156)."""
 
@@ -233,8 +256,7 @@ class SetAbstraction(nn.Module):
         B = xyz.shape[0]
         _, new_xyz = _sample(xyz, self.npoint)
         idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
-        rows, perm = rowmlp.group_rows(xyz, new_xyz, feat, idx)
-        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, rows, pool=self.nsample, perm=perm)
+        x = _grouped_mlp(self.mlp_convs, self.mlp_bns, xyz, new_xyz, feat, idx)
         return new_xyz, x.view(B, self.npoint, -1).transpose(1, 2)
 
 
@@ -270,8 +292,7 @@ class MultiScaleSetAbstraction(nn.Module):
         B = xyz.shape[0]
         outs = []
         for i, idx in enumerate(idx_list):
-            rows, perm = rowmlp.group_rows(xyz, new_xyz, feat, idx)
-            x = rowmlp.mlp_rows(self.conv_blocks[i], self.bn_blocks[i], rows, pool=idx.shape[2], perm=perm)
+            x = _grouped_mlp(self.conv_blocks[i], self.bn_blocks[i], xyz, new_xyz, feat, idx)
             outs.append(x.view(B, self.npoint, -1))
         return new_xyz, torch.cat(outs, dim=2).transpose(1, 2)
 

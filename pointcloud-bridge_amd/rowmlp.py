@@ -275,7 +275,7 @@ class _FusedStack(torch.autograd.Function):
             arg = None
         with torch.cuda.device(dev):
             _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, x.data_ptr(), R, Kp, perm, act, pool, int(need_dx),
-                    int(stat_repeat), wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
+                    int(stat_repeat), 0, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
                     0 if arg is None else arg.data_ptr())
         ctx.save_for_backward(x, arg, ybuf, stz, wbuf, *[t[0] for t in layers])
         ctx.cfg = (act, pool, perm, L, need_dx, [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
@@ -317,10 +317,133 @@ class _FusedStack(torch.autograd.Function):
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _launch("pcb_mlp_stack_backward", 0, L, desc, x.data_ptr(), g.data_ptr(),
-                    0 if arg is None else arg.data_ptr(), R, Kp, perm, act, pool, int(need_dx), wbuf.data_ptr(),
+                    0 if arg is None else arg.data_ptr(), R, Kp, perm, act, pool, int(need_dx), 0, wbuf.data_ptr(),
                     stz.data_ptr(), parts.data_ptr(), ws.data_ptr(), 0 if dzbuf is None else dzbuf.data_ptr(),
                     0 if dx is None else dx.data_ptr())
         return (dx, None, None, None, None, None, *grads)
+
+
+class _GatheredStack(torch.autograd.Function):
+    """A grouped stack whose FIRST layer is evaluated per point and gathered (csrc/gatherlin.hip):
+    y0[(s,j)] = u[idx[s,j]] + v[s] with the per-point products u [B*N,C0], v [B*S,C0] (fp32,
+    computed by the caller with ordinary, differentiable matmuls), then BatchNorm + activation and
+    the remaining layers / pooling exactly as _FusedStack.  Backward returns du, dv; autograd takes
+    them through the caller's matmuls to the first conv's weight and to the features.
+
+    Flat argument list: u, v, idx, ns, act, pool, L, then per layer (weight, bias, gamma, beta,
+    running_mean, running_var, training, momentum, eps); layer 0's weight is None."""
+
+    NPER = 9
+
+    @staticmethod
+    def forward(ctx, u, v, idx, ns, act, pool, L, *flat):
+        dev = u.device
+        B, S = idx.shape[0], idx.shape[1]
+        N = u.shape[0] // B
+        R = B * S * ns
+        layers = [flat[i * _GatheredStack.NPER:(i + 1) * _GatheredStack.NPER] for i in range(L)]
+        widths = [u.shape[1]] + [t[0].shape[0] for t in layers[1:]]
+        lib = _lib.load()
+        ybuf = torch.empty(R * sum(widths), dtype=torch.bfloat16, device=dev)
+        stz = torch.empty(10 * sum(widths), dtype=torch.float32, device=dev)
+        parts = torch.empty(max(_MAX_PARTS, 1024) * 2 * max(widths), dtype=torch.float32, device=dev)
+        desc = _stack_desc(layers, widths, ybuf, R)
+        nw = lib.pcb_mlp_stack_wbuf_elems(L, desc, 0, 0)
+        wbuf = torch.empty(max(nw, 1), dtype=torch.bfloat16, device=dev)
+        fdesc = (ctypes.c_double * (2 * L))(*[float(x) for t in layers for x in (t[7], t[8])])
+        gather = (ctypes.c_longlong * 8)(u.data_ptr(), v.data_ptr(), idx.data_ptr(), B, N, S, ns, 0)
+        C = widths[-1]
+        if pool:
+            out = torch.empty(R // pool, C, dtype=torch.bfloat16, device=dev)
+            arg = torch.empty(R // pool, C, dtype=torch.uint8, device=dev)
+        else:
+            out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+            arg = None
+        with torch.cuda.device(dev):
+            _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, 0, R, 0, 0, act, pool, 0, 1, gather,
+                    wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
+                    0 if arg is None else arg.data_ptr())
+        ctx.save_for_backward(idx, arg, ybuf, stz, wbuf, *[t[0] for t in layers[1:]])
+        ctx.cfg = (act, pool, L, ns, B, N, S, widths,
+                   [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        act, pool, L, ns, B, N, S, widths, flags = ctx.cfg
+        saved = ctx.saved_tensors
+        idx, arg, ybuf, stz, wbuf = saved[:5]
+        weights = [None] + list(saved[5:5 + L - 1])
+        dev = idx.device
+        R = B * S * ns
+        lib = _lib.load()
+        g = g.float().contiguous() if pool else g.to(torch.bfloat16).contiguous()
+        grads = [None] * (L * _GatheredStack.NPER)
+        outs, ws_elems = [], 0
+        for l in range(L):
+            C = widths[l]
+            has_bias, has_affine, _ = flags[l]
+            base = l * _GatheredStack.NPER
+            dw = None
+            if l and ctx.needs_input_grad[7 + base]:
+                dw = grads[base + 0] = torch.empty_like(weights[l])
+                ws_elems = max(ws_elems, lib.pcb_gemm_tn_workspace(R, C, widths[l - 1]))
+            dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev) if has_bias else None
+            dgamma = grads[base + 2] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
+            dbeta = grads[base + 3] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
+            outs.append((dw, dgamma, dbeta, dbias))
+        layers = [(weights[l], None, None, None, None, None, flags[l][2]) for l in range(L)]
+        desc = _stack_desc(layers, widths, ybuf, R, outs)
+        du = torch.empty(B * N, widths[0], dtype=torch.float32, device=dev)   # zeroed by the library
+        dv = torch.empty(B * S, widths[0], dtype=torch.float32, device=dev)
+        gather = (ctypes.c_longlong * 8)(du.data_ptr(), dv.data_ptr(), idx.data_ptr(), B, N, S, ns, 0)
+        dzbuf = torch.empty(2 * R * max([8] + widths[:-1]), dtype=torch.bfloat16, device=dev) if L > 1 else None
+        parts = torch.empty(max(_MAX_PARTS, 1024) * 2 * max(widths), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _launch("pcb_mlp_stack_backward", 0, L, desc, 0, g.data_ptr(), 0 if arg is None else arg.data_ptr(), R, 0,
+                    0, act, pool, 0, gather, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), ws.data_ptr(),
+                    0 if dzbuf is None else dzbuf.data_ptr(), 0)
+        return (du, dv, None, None, None, None, None, *grads)
+
+
+def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0):
+    """bf16 fused engine: the stack convs/bns applied to grouped rows whose first-layer products are
+    given per point: u [B*N, C0] fp32 (source points), v [B*S, C0] fp32 (centroids), idx [B,S,ns]
+    int64; row (s,j) of layer 0's output is u[idx[s,j]] + v[s].  convs[0] contributes only its bias
+    (its weight went into u, v).  Returns [B*S*ns, C] rows or, with pool = ns, [B*S, C]."""
+    B, S, ns = idx.shape
+    if pool not in (0, ns):
+        raise ValueError("a gathered stack pools over its own neighbour axis")
+    counted = [bn.num_batches_tracked for bn in bns
+               if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None
+               and bn.momentum is not None]
+    if counted:
+        torch._foreach_add_(counted, 1)
+    flat = []
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
+        training = bn.training or (bn.running_mean is None and bn.running_var is None)
+        track = bn.track_running_stats and bn.running_mean is not None
+        flat += [conv.weight if i else None, conv.bias, bn.weight, bn.bias,
+                 bn.running_mean if (track or not training) else None,
+                 bn.running_var if (track or not training) else None,
+                 training, momentum, bn.eps]
+    return _GatheredStack.apply(u.contiguous(), v.contiguous(), idx.contiguous(), ns, act, pool, len(convs), *flat)
+
+
+_GATHERED = True
+
+
+def set_gathered(flag):
+    """Enable / disable the gathered first layer (A/B timing and the equivalence tests)."""
+    global _GATHERED
+    _GATHERED = bool(flag)
+
+
+def gathered_ok(convs, bns):
+    """The gathered first layer needs the fused bf16 engine and 8-aligned layer widths."""
+    return _GATHERED and is_bf16() and _ENGINE == "fused" and _stack_fusable(convs, bns)
 
 
 _MAX_PARTS = 768  # upper bound of pcb_gemm_nt_partials (persistent workgroups of a gemm_nt launch)
@@ -332,14 +455,15 @@ def _stack_desc(layers, widths, ybuf, R, outs=None):
     ybase = ybuf.data_ptr()
     for l, t in enumerate(layers):
         w, bias, gamma, beta, rm, rv, training = t[:7]
-        if not (w.is_contiguous() and w.dtype == torch.float32):
+        if w is not None and not (w.is_contiguous() and w.dtype == torch.float32):
             raise TypeError("fused bf16 layers expect contiguous fp32 master weights")
         C = widths[l]
         o = outs[l] if outs is not None else (None, None, None, None)
-        vals += [w.data_ptr(),
+        vals += [0 if w is None else w.data_ptr(),
                  0 if bias is None else bias.data_ptr(), 0 if gamma is None else gamma.data_ptr(),
                  0 if beta is None else beta.data_ptr(), 0 if rm is None else rm.data_ptr(),
-                 0 if rv is None else rv.data_ptr(), C, w.numel() // C, int(bool(training)), ybase + 2 * yoff,
+                 0 if rv is None else rv.data_ptr(), C, 0 if w is None else w.numel() // C, int(bool(training)),
+                 ybase + 2 * yoff,
                  0 if o[0] is None else o[0].data_ptr(), 0 if o[1] is None else o[1].data_ptr(),
                  0 if o[2] is None else o[2].data_ptr(), 0 if o[3] is None else o[3].data_ptr(), 0, 0]
         yoff += R * C
