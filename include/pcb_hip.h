@@ -258,6 +258,10 @@ int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale
                      int ns, int act, const void *w, long R, int N, int K, void *out, float *sums,
                      void *stream);
 
+/* out[R,N] fp32 = a[R,K] (bf16) . w[N,K]^T (bf16): the plain GEMM with an UNROUNDED result, for the
+ * per-point products of csrc/gatherlin.hip (replaces torch.matmul on R = B*N rows). */
+int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int N, int K, float *out, void *stream);
+
 /* Number of per-workgroup statistics slabs pcb_gemm_nt_bf16 writes for these sizes. */
 int pcb_gemm_nt_partials(int pro, long R, int N);
 
@@ -385,25 +389,33 @@ int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const vo
  * convolution of [x_j - c_s | f_j] (sample_and_group, models/pointnet2_utils.py:51-58) or
  * [x_j - x_i | x_i] (get_graph_feature, models/DGCNN.py:90-107) equals u[idx(s,j)] + v[s] with the
  * per-point products u (N rows per scene) and v (S rows per scene), both fp32 [.,C].
- *   pcb_gather_add_bf16   y[r,:] = bf16(u[b*N + idx[r],:] + v[r/ns,:]), r over B*S*ns rows, and the
- *                         column sums / sums of squares of y into [pcb_gather_add_partials(R,C)][2][C]
- *                         slabs for pcb_bn_finalize.
+ *   pcb_gather_add_bf16   y[r,:] = bf16(u[b*N + idx[r],:] + v[r/ns,:] + Wx (xyz[b*N + idx[r]] - ctr[r/ns])),
+ *                         r over B*S*ns rows, and the column sums / sums of squares of y into
+ *                         [pcb_gather_add_partials(R,C)][2][C] slabs for pcb_bn_finalize.  v may be
+ *                         NULL; the coordinate term (the reference's fp32 difference x_j - c_s times
+ *                         the first 3 weight columns, wx [C,3] with row stride ldw) is used when wx
+ *                         is not NULL (xyz [B,N,3], ctr [B,S,3] fp32).
  *   pcb_scatter_dy_bf16   backward: dy = the layer's BatchNorm/activation backward built from
  *                         (dz, y) or, pooled != 0, from (dout, argmax, y) of a max over the same ns
  *                         rows, with scale/shift/p/q as in pcb_gemm_nt_bf16 pro 2/3;
  *                         du[b*N + idx[r],:] += dy[r,:] (fp32 atomics, du zeroed by the caller),
- *                         dv[r/ns,:] = sum over the group (overwritten).
- * The stack calls take these through `gather` (NULL = ordinary stack): 8 int64 on the host,
- *   {u | du, v | dv, idx, B, N, S, ns, 0}  (forward reads u, v; backward writes du, dv and zeroes du);
+ *                         dv[r/ns,:] = sum over the group (overwritten; may be NULL),
+ *                         dwx (may be NULL): fp32 [33][C][3], all zeroed by the caller; slab 0 receives
+ *                         dWx[c,:] = sum_r dy[r,c] (x_j - c_s), slabs 1..32 are scratch (the atomic adds
+ *                         are spread over them and summed at the end).
+ * The stack calls take these through `gather` (NULL = ordinary stack): 12 int64 on the host,
+ *   {u | du, v | dv, idx, B, N, S, ns, xyz, ctr, wx | dwx, ldw, 0}  (forward reads u, v, wx; backward
+ *   writes du, dv, dwx ([33][C][3], result in slab 0) and zeroes du, dwx first);
  * layer 0 of desc then carries no weight (slots [0],[7],[10] unused) and x, Kp, perm, dx are ignored.
  */
 int pcb_gather_add_partials(long R, int C);
 int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S, int ns, int C,
-                        void *y, float *sums, void *stream);
+                        const float *xyz, const float *ctr, const float *wx, int ldw, void *y, float *sums,
+                        void *stream);
 int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *scale, const float *shift,
                         const float *p, const float *q, const float *dout, const unsigned char *argmax, int act,
-                        const int64_t *idx, int B, int N, int S, int ns, int C, float *du, float *dv,
-                        void *stream);
+                        const int64_t *idx, int B, int N, int S, int ns, int C, const float *xyz,
+                        const float *ctr, float *du, float *dv, float *dwx, void *stream);
 
 /*
  * HIP-event timing of the gemm_nt kernel family (pcb_gemm_nt_bf16 / pcb_gemm_nt_red_bf16, also when

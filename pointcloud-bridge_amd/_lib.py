@@ -31,6 +31,7 @@ SIGNATURES = {
     "pcb_colstats_bf16": [_p, _l, _i, _p, _p],
     "pcb_bn_finalize": [_p, _i, _l, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p],
     "pcb_gemm_nt_partials": [_i, _l, _i],
+    "pcb_gemm_nt_f32out_bf16": [_p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_bf16": [_p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_max_bf16": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
     "pcb_bn_act_bwd_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
@@ -50,8 +51,8 @@ SIGNATURES = {
     "pcb_mlp_stack_forward": [_i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "pcb_mlp_stack_backward": [_i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "pcb_gather_add_partials": [_l, _i],
-    "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
-    "pcb_scatter_dy_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p],
+    "pcb_scatter_dy_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "pcb_timer_start": [],
     "pcb_timer_enable": [_i],
     "pcb_timer_stop": [_p, _p, _p],

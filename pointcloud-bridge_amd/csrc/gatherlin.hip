@@ -12,7 +12,12 @@
 // tensor [S*ns, 3+C] is never written.  u, v are fp32 (the difference of two nearby points must
 // not be taken between bf16-rounded products); the caller computes them with ordinary GEMMs.
 //
-//   gather_add   y[r,:] = bf16(u[src(r),:] + v[r/ns,:])  + the BatchNorm statistics of y (slabs)
+// The coordinate part of a set-abstraction row can also stay exactly as the reference has it,
+// Wx (x_j - c_s) with the difference taken in fp32 first: gather_add then takes xyz, the centroids
+// and Wx instead of v (u = F Wf^T only), and scatter_dy returns dWx = sum_r dy[r] (x_j - c_s)^T.
+//
+//   gather_add   y[r,:] = bf16(u[src(r),:] + v[r/ns,:] + Wx (x_j - c_s))  + the BatchNorm
+//                statistics of y (slabs); v and the Wx term are optional
 //   scatter_dy   backward: dy[r,:] = BatchNorm/activation backward of the layer, built on the fly
 //                from (dz | dout+argmax, y) exactly as the GEMM prologues of gemm.hip do;
 //                du[src(r),:] += dy[r,:] (fp32 atomics; runs of equal src are combined first: ball
@@ -24,6 +29,7 @@ namespace {
 
 typedef unsigned short u16;
 constexpr int kThreads = 256;
+constexpr int kDwxSlabs = 32;
 
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
@@ -48,7 +54,10 @@ __global__ __launch_bounds__(kThreads) void gather_add_kernel(const float *__res
                                                                const float *__restrict__ v,
                                                                const int64_t *__restrict__ idx, int N, int S,
                                                                int ns, int C, long R, u16 *__restrict__ y,
-                                                               float *__restrict__ sums)
+                                                               float *__restrict__ sums,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ ctr,
+                                                               const float *__restrict__ wx, int ldw)
 {
     __shared__ float red[kThreads * 16];
     const int CT = C >> 3;
@@ -57,13 +66,32 @@ __global__ __launch_bounds__(kThreads) void gather_add_kernel(const float *__res
     const int rl = threadIdx.x / CT;
     const long per_scene = (long)S * ns;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float w0[8], w1[8], w2[8];  // Wx rows of this lane's 8 columns
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool on = wx != nullptr && rl < RT;
+        w0[i] = on ? wx[(long)(cc * 8 + i) * ldw + 0] : 0.0f;
+        w1[i] = on ? wx[(long)(cc * 8 + i) * ldw + 1] : 0.0f;
+        w2[i] = on ? wx[(long)(cc * 8 + i) * ldw + 2] : 0.0f;
+    }
     if (rl < RT) {
         for (long r = (long)blockIdx.x * RT + rl; r < R; r += (long)gridDim.x * RT) {
             const long b = r / per_scene;
             const long src = b * N + clamp_index(idx[r], N);
             float a[8], c[8];
             load8(u + src * C + cc * 8, a);
-            load8(v + (r / ns) * C + cc * 8, c);
+            if (v) {
+                load8(v + (r / ns) * C + cc * 8, c);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c[i] = 0.0f;
+            }
+            if (wx) {
+                const float *pj = xyz + src * 3, *pc = ctr + (r / ns) * 3;
+                const float d0 = pj[0] - pc[0], d1 = pj[1] - pc[1], d2 = pj[2] - pc[2];  // as reference :56
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c[i] += fmaf(w2[i], d2, fmaf(w1[i], d1, w0[i] * d0));
+            }
             uint4 o;
             uint32_t w[4];
 #pragma unroll
@@ -95,7 +123,9 @@ __global__ __launch_bounds__(kThreads) void gather_add_kernel(const float *__res
     }
 }
 
-// One lane per (centroid g, column chunk): walks the ns rows of the group.
+// One lane per (centroid g, column c), column fastest: a wave's loads cover whole row segments and
+// -- what matters -- its atomics hit consecutive addresses (the same kernel with 8 columns per lane,
+// i.e. lanes 32 bytes apart, ran ten times slower: float atomics are resolved per cache line).
 //   POOLED = 0: dz rows (bf16) given;  POOLED = 1: dout [G,C] fp32 + argmax [G,C] uint8 of a layer
 //   max-pooled over the same ns rows.
 template <int POOLED>
@@ -104,62 +134,90 @@ __global__ __launch_bounds__(kThreads) void scatter_dy_kernel(
     const float *__restrict__ shift, const float *__restrict__ p, const float *__restrict__ q,
     const float *__restrict__ dout, const unsigned char *__restrict__ arg, float slope,
     const int64_t *__restrict__ idx, int N, int S, int ns, int C, long G, float *__restrict__ du,
-    float *__restrict__ dv)
+    float *__restrict__ dv, const float *__restrict__ xyz, const float *__restrict__ ctr,
+    float *__restrict__ dwx)
 {
-    const int CT = C >> 3;
-    const long total = G * CT;
-    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
-        const long g = e / CT;
-        const int c0 = (int)(e - g * CT) * 8;
+    // the grid stride is a multiple of C (see the launcher): a lane keeps its column for good
+    __shared__ float red[kThreads * 3];
+    const long total = G * C;
+    const long first = (long)blockIdx.x * kThreads + threadIdx.x;
+    const int c = (int)(first % C);
+    const float sc = scale[c], sh = shift[c], pp = p[c], qq = q[c];
+    float wacc0 = 0.0f, wacc1 = 0.0f, wacc2 = 0.0f;  // dWx[c][0..2]
+    for (long e = first; e < total; e += (long)gridDim.x * kThreads) {
+        const long g = e / C;
         const long b = g / S;
-        float sc[8], sh[8], pp[8], qq[8], d[8];
-        load8(scale + c0, sc);
-        load8(shift + c0, sh);
-        load8(p + c0, pp);
-        load8(q + c0, qq);
-        unsigned long long am = 0;
+        float d = 0.0f;
+        int am = -1;
         if (POOLED) {
-            load8(dout + g * C + c0, d);
-            am = *reinterpret_cast<const unsigned long long *>(arg + g * C + c0);
+            d = dout[e];
+            am = arg[e];
         }
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dv: the whole group
-        float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // du: the current run of equal source indices
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        if (dwx) {
+            c0 = ctr[g * 3 + 0];
+            c1 = ctr[g * 3 + 1];
+            c2 = ctr[g * 3 + 2];
+        }
+        float acc = 0.0f;   // dv: the whole group
+        float run = 0.0f;   // du: the current run of equal source indices
         long run_src = -1;
+        const long r0 = g * ns;
         for (int j = 0; j < ns; ++j) {
-            const long r = g * ns + j;
+            const long r = r0 + j;
             const long src = b * N + clamp_index(idx[r], N);
-            float yv[8], f[8];
-            unpack8(*reinterpret_cast<const uint4 *>(y + r * C + c0), yv);
-            if (POOLED) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) f[i] = ((int)((am >> (8 * i)) & 0xff) == j) ? d[i] : 0.0f;
-            } else {
-                unpack8(*reinterpret_cast<const uint4 *>(dz + r * C + c0), f);
-            }
-            if (src != run_src) {
-                if (run_src >= 0) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) atomicAdd(&du[run_src * C + c0 + i], run[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) run[i] = 0.0f;
+            const float yv = bf2f(y[r * C + c]);
+            const float f = POOLED ? (j == am ? d : 0.0f) : bf2f(dz[r * C + c]);
+            if (src != run_src) {  // uniform over the lanes of a group
+                if (run_src >= 0) atomicAdd(&du[run_src * C + c], run);
+                run = 0.0f;
                 run_src = src;
             }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float g1 = f[i] * (fmaf(yv[i], sc[i], sh[i]) > 0.0f ? 1.0f : slope);
-                const float dy = fmaf(sc[i], g1, fmaf(pp[i], yv[i], qq[i]));
-                run[i] += dy;
-                acc[i] += dy;
+            const float g1 = f * (fmaf(yv, sc, sh) > 0.0f ? 1.0f : slope);
+            const float dy = fmaf(sc, g1, fmaf(pp, yv, qq));
+            run += dy;
+            acc += dy;
+            if (dwx) {
+                wacc0 = fmaf(dy, xyz[src * 3 + 0] - c0, wacc0);
+                wacc1 = fmaf(dy, xyz[src * 3 + 1] - c1, wacc1);
+                wacc2 = fmaf(dy, xyz[src * 3 + 2] - c2, wacc2);
             }
         }
-        if (run_src >= 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) atomicAdd(&du[run_src * C + c0 + i], run[i]);
-        }
-        *reinterpret_cast<float4 *>(dv + g * C + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4 *>(dv + g * C + c0 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        if (run_src >= 0) atomicAdd(&du[run_src * C + c], run);
+        if (dv) dv[e] = acc;
     }
+    if (dwx) {
+        // lanes of the block holding the same column meet in LDS; one atomic per column and block
+        red[threadIdx.x * 3 + 0] = wacc0;
+        red[threadIdx.x * 3 + 1] = wacc1;
+        red[threadIdx.x * 3 + 2] = wacc2;
+        __syncthreads();
+        if (threadIdx.x < C && first < total) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+            for (int t = threadIdx.x; t < kThreads; t += C) {
+                if ((long)blockIdx.x * kThreads + t < total) {
+                    a0 += red[t * 3 + 0];
+                    a1 += red[t * 3 + 1];
+                    a2 += red[t * 3 + 2];
+                }
+            }
+            // thousands of workgroups adding into 3C addresses would queue up on them: the adds are
+            // spread over kDwxSlabs copies (slabs 1..), summed into slab 0 by sum_slabs_kernel
+            float *slab = dwx + (long)(1 + blockIdx.x % kDwxSlabs) * C * 3;
+            atomicAdd(&slab[c * 3 + 0], a0);
+            atomicAdd(&slab[c * 3 + 1], a1);
+            atomicAdd(&slab[c * 3 + 2], a2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void sum_slabs_kernel(float *__restrict__ dwx, int elems)
+{
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    if (e >= elems) return;
+    float a = 0.0f;
+    for (int k = 1; k <= kDwxSlabs; ++k) a += dwx[(long)k * elems + e];
+    dwx[e] = a;
 }
 
 inline long gather_add_grid(long R, int C)
@@ -180,34 +238,45 @@ extern "C" int pcb_gather_add_partials(long R, int C)
 }
 
 extern "C" int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S,
-                                   int ns, int C, void *y, float *sums, void *stream)
+                                   int ns, int C, const float *xyz, const float *ctr, const float *wx, int ldw,
+                                   void *y, float *sums, void *stream)
 {
-    if (!u || !v || !idx || !y || !sums || B <= 0 || N <= 0 || S <= 0 || ns <= 0) return PCB_ERR_INVALID_ARG;
+    if (!u || !idx || !y || !sums || B <= 0 || N <= 0 || S <= 0 || ns <= 0) return PCB_ERR_INVALID_ARG;
+    if (wx && (!xyz || !ctr || ldw < 3)) return PCB_ERR_INVALID_ARG;
     if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
     const long R = (long)B * S * ns;
     hipLaunchKernelGGL(gather_add_kernel, dim3((unsigned)gather_add_grid(R, C)), dim3(kThreads), 0,
-                       (hipStream_t)stream, u, v, idx, N, S, ns, C, R, (u16 *)y, sums);
+                       (hipStream_t)stream, u, v, idx, N, S, ns, C, R, (u16 *)y, sums, xyz, ctr, wx, ldw);
     return pcb_check_launch();
 }
 
 extern "C" int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *scale,
                                    const float *shift, const float *p, const float *q, const float *dout,
                                    const unsigned char *argmax, int act, const int64_t *idx, int B, int N,
-                                   int S, int ns, int C, float *du, float *dv, void *stream)
+                                   int S, int ns, int C, const float *xyz, const float *ctr, float *du, float *dv,
+                                   float *dwx, void *stream)
 {
-    if (!y || !scale || !shift || !p || !q || !idx || !du || !dv || B <= 0 || N <= 0 || S <= 0 || ns <= 0)
+    if (!y || !scale || !shift || !p || !q || !idx || !du || B <= 0 || N <= 0 || S <= 0 || ns <= 0)
         return PCB_ERR_INVALID_ARG;
     if (pooled ? (!dout || !argmax || ns > 255) : !dz) return PCB_ERR_INVALID_ARG;
+    if (dwx && (!xyz || !ctr)) return PCB_ERR_INVALID_ARG;
     if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
     const long G = (long)B * S;
-    long blocks = (G * (C >> 3) + kThreads - 1) / kThreads;
-    if (blocks > 8192) blocks = 8192;
+    // grid * 256 must be a multiple of C (a lane keeps its column): multiples of m = C / gcd(C, 256)
+    int gcd = C, t = kThreads;
+    while (t) { const int r = gcd % t; gcd = t; t = r; }
+    const long m = C / gcd;
+    long blocks = (G * C + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    blocks = (blocks + m - 1) / m * m;
     hipStream_t st = (hipStream_t)stream;
     if (pooled)
         hipLaunchKernelGGL(scatter_dy_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), 0, st, (const u16 *)dz,
-                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv);
+                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv, xyz, ctr, dwx);
     else
         hipLaunchKernelGGL(scatter_dy_kernel<0>, dim3((unsigned)blocks), dim3(kThreads), 0, st, (const u16 *)dz,
-                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv);
+                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv, xyz, ctr, dwx);
+    if (dwx)
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((3 * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, dwx, 3 * C);
     return pcb_check_launch();
 }

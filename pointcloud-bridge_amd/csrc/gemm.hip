@@ -188,7 +188,7 @@ struct RedArgs {
     int act;
 };
 
-template <int PRO, int STATS, int RED>
+template <int PRO, int STATS, int RED, int OUT32 = 0>
 __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
                                                        int N, int K, u16 *__restrict__ out,
                                                        float *__restrict__ sums, RedArgs red_arg)
@@ -302,6 +302,23 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
         // and stores it back as 16-byte row segments -- 8 wide stores per lane instead of 64
         // two-byte ones.
         const long m0 = tile * NT_BM;
+        if (OUT32) {
+            // fp32 output (`out` then points to floats): straight from the accumulators, 32 lanes
+            // writing 128 contiguous bytes of a row.  For the small per-point GEMMs whose results
+            // are differenced afterwards (csrc/gatherlin.hip) and must not be rounded to bf16.
+            float *const o32 = reinterpret_cast<float *>(out);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const long r = m0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    if (r < R && n < N) o32[r * N + n] = acc[j][i];
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         u16 *const stage = smem + wave * (32 * NT_OUT_LD);
         const long rows_here = R - m0 < NT_BM ? R - m0 : NT_BM;
         const __amdgpu_buffer_rsrc_t orsrc =
@@ -896,6 +913,19 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
         default: launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
     }
     pcb_timer_end(st, timed, bytes, pro, R, N, K);
+    return pcb_check_launch();
+}
+
+extern "C" int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int N, int K, float *out, void *stream)
+{
+    if (!a || !w || !out || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
+    const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
+    const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
+    const dim3 grid((unsigned)nt_grid_x(PRO_PLAIN, R, N), ny);
+    const RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0, 1>), grid, dim3(256), 0, (hipStream_t)stream, A, (const u16 *)w, R, N,
+                       K, (u16 *)out, (float *)nullptr, none);
     return pcb_check_launch();
 }
 

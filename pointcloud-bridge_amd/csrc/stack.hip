@@ -226,9 +226,12 @@ extern "C" long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, i
 
 namespace {
 struct Gather {
-    float *u, *v;  // forward: u, v;  backward: du, dv
+    float *u, *v;  // forward: u, v (v optional);  backward: du, dv
     const int64_t *idx;
     int B, N, S, ns;
+    const float *xyz, *ctr;  // optional coordinate term Wx (x_j - c_s)
+    float *wx;               // forward: Wx [C,3] with row stride ldw;  backward: dWx [C,3]
+    int ldw;
 };
 bool parse_gather(const long long *g, Gather *out)
 {
@@ -240,6 +243,10 @@ bool parse_gather(const long long *g, Gather *out)
     out->N = (int)g[4];
     out->S = (int)g[5];
     out->ns = (int)g[6];
+    out->xyz = ptr<const float>(g[7]);
+    out->ctr = ptr<const float>(g[8]);
+    out->wx = ptr<float>(g[9]);
+    out->ldw = (int)g[10];
     return true;
 }
 }  // namespace
@@ -253,7 +260,7 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
     Gather ga;
     const bool gathered = parse_gather(gather, &ga);
     if (gathered) {
-        if (!ga.u || !ga.v || !ga.idx || (long)ga.B * ga.S * ga.ns != R || !parts) return PCB_ERR_INVALID_ARG;
+        if (!ga.u || !ga.idx || (long)ga.B * ga.S * ga.ns != R || !parts) return PCB_ERR_INVALID_ARG;
         Kp = 0;
     }
     PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, ly));
@@ -295,7 +302,8 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
         const float *pshift = l ? row(stz, ly[l - 1], 3) : nullptr;
         int nparts;
         if (gathered && l == 0) {
-            PCB_TRY(pcb_gather_add_bf16(ga.u, ga.v, ga.idx, ga.B, ga.N, ga.S, ga.ns, a.C, a.y, parts, stream));
+            PCB_TRY(pcb_gather_add_bf16(ga.u, ga.v, ga.idx, ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.wx, ga.ldw,
+                                        a.y, parts, stream));
             nparts = pcb_gather_add_partials(R, a.C);
         } else {
             PCB_TRY(pcb_gemm_nt_bf16(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0,
@@ -325,7 +333,7 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
     Gather ga;
     const bool gathered = parse_gather(gather, &ga);
     if (gathered) {
-        if (!ga.u || !ga.v || !ga.idx || (long)ga.B * ga.S * ga.ns != R || dx) return PCB_ERR_INVALID_ARG;
+        if (!ga.u || !ga.idx || (long)ga.B * ga.S * ga.ns != R || dx) return PCB_ERR_INVALID_ARG;
         Kp = 0;
     }
     PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, ly));
@@ -368,8 +376,10 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
             if (pooled && pool != ga.ns) return PCB_ERR_INVALID_ARG;
             if (hipMemsetAsync(ga.u, 0, sizeof(float) * (size_t)ga.B * ga.N * a.C, (hipStream_t)stream) != hipSuccess)
                 return PCB_ERR_LAUNCH;
+            if (ga.wx && hipMemsetAsync(ga.wx, 0, sizeof(float) * 3 * a.C * 33, (hipStream_t)stream) != hipSuccess)
+                return PCB_ERR_LAUNCH;
             PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx, ga.B,
-                                        ga.N, ga.S, ga.ns, a.C, ga.u, ga.v, stream));
+                                        ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.u, ga.v, ga.wx, stream));
             break;
         }
         // weight gradient, in the parameter's own layout

@@ -60,14 +60,14 @@ class DGCNN(nn.Module):
         B, N, D = x.shape
         xf = x.float()
         idx = ops.knn(xf, k)  # the graph is always built from fp32 distances
-        if x.requires_grad and D >= 32 and rowmlp.gathered_ok([block[0]], [block[1]]):
+        if x.requires_grad and D >= 32 and D % 8 == 0 and rowmlp.gathered_ok([block[0]], [block[1]]):
             # W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i: per-point products, gathered by the graph
             # (rowmlp.gathered_mlp); the [B*N*k, 2D] edge tensor is never written
             w = block[0].weight.view(block[0].out_channels, 2 * D)
             wa, wb = w[:, :D], w[:, D:]
-            xr = xf.reshape(B * N, D)
-            y = rowmlp.gathered_mlp([block[0]], [block[1]], xr @ wa.t(), xr @ (wb - wa).t(), idx,
-                                    rowmlp.ACT_LEAKY, pool=k)
+            xr = x.reshape(B * N, D)
+            y = rowmlp.gathered_mlp([block[0]], [block[1]], rowmlp.point_linear(xr, wa),
+                                    rowmlp.point_linear(xr, wb - wa), idx, rowmlp.ACT_LEAKY, pool=k)
             return y.view(B, N, -1)
         e = ops.edge_features(xf, idx).view(B * N * k, 2 * D)
         y = rowmlp.conv_bn_act(block[0], block[1], e, rowmlp.ACT_LEAKY, pool=k)

@@ -219,19 +219,19 @@ def _grouped_mlp(convs, bns, xyz, new_xyz, feat, idx):
     (reference :51-58 + :149-154 / :342-356) -> [B*S, C] rows.
 
     bf16 mode with differentiable features of useful width: the first 1x1 conv is linear in
-    [x_j - c_s | f_j], so it is evaluated per point (u = X Wx^T + F Wf^T on N rows, v = -C Wx^T on S
-    rows, fp32) and the rows y0[s,j] = u[idx[s,j]] + v[s] are gathered (rowmlp.gathered_mlp): the
+    [x_j - c_s | f_j], so its feature part is evaluated per point (u = F Wf^T on N rows,
+    rowmlp.point_linear) and the rows y0[s,j] = u[idx[s,j]] + Wx (x_j - c_s) are gathered
+    (rowmlp.gathered_mlp; the coordinate difference is formed in fp32 as in the reference): the
     grouped tensor is never written and the first GEMM, its input gradient and the scatter of a
     (3+C)-wide row gradient shrink to C0-wide gathers/scatters.  Otherwise rows are grouped first."""
     B, S, ns = idx.shape
     cf = 0 if feat is None else feat.shape[2]
-    if feat is not None and feat.requires_grad and cf >= 32 and rowmlp.gathered_ok(convs, bns):
+    if (feat is not None and feat.requires_grad and cf >= 32 and cf % 8 == 0
+            and rowmlp.gathered_ok(convs, bns)):
         N = xyz.shape[1]
         w0 = convs[0].weight.view(convs[0].out_channels, 3 + cf)
-        wx, wf = w0[:, :3], w0[:, 3:]
-        u = torch.addmm(xyz.reshape(B * N, 3) @ wx.t(), feat.reshape(B * N, cf).float(), wf.t())
-        v = -(new_xyz.reshape(B * S, 3) @ wx.t())
-        return rowmlp.gathered_mlp(convs, bns, u, v, idx, pool=ns)
+        u = rowmlp.point_linear(feat.reshape(B * N, cf), w0[:, 3:])
+        return rowmlp.gathered_mlp(convs, bns, u, None, idx, pool=ns, wx=w0[:, :3], xyz=xyz, ctr=new_xyz)
     rows, perm = rowmlp.group_rows(xyz, new_xyz, feat, idx)
     return rowmlp.mlp_rows(convs, bns, rows, pool=ns, perm=perm)
 

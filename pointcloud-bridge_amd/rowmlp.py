@@ -323,20 +323,71 @@ class _FusedStack(torch.autograd.Function):
         return (dx, None, None, None, None, None, *grads)
 
 
-class _GatheredStack(torch.autograd.Function):
-    """A grouped stack whose FIRST layer is evaluated per point and gathered (csrc/gatherlin.hip):
-    y0[(s,j)] = u[idx[s,j]] + v[s] with the per-point products u [B*N,C0], v [B*S,C0] (fp32,
-    computed by the caller with ordinary, differentiable matmuls), then BatchNorm + activation and
-    the remaining layers / pooling exactly as _FusedStack.  Backward returns du, dv; autograd takes
-    them through the caller's matmuls to the first conv's weight and to the features.
-
-    Flat argument list: u, v, idx, ns, act, pool, L, then per layer (weight, bias, gamma, beta,
-    running_mean, running_var, training, momentum, eps); layer 0's weight is None."""
-
-    NPER = 9
+class _PointLinear(torch.autograd.Function):
+    """out [n, C] fp32 = x [n, K] (bf16) @ w [C, K]^T (fp32 master weight, bf16 operand): the small
+    per-point GEMM in front of a gathered stack, with an UNROUNDED result (hipBLASLt's fp32 kernels
+    run these skinny shapes at a fraction of the bandwidth; a bf16 result would lose the difference
+    of two nearby points).  Backward: dW by the split-row MFMA kernel, dx as bf16 rows."""
 
     @staticmethod
-    def forward(ctx, u, v, idx, ns, act, pool, L, *flat):
+    def forward(ctx, x, w):
+        n, K = x.shape
+        C = w.shape[0]
+        dev = x.device
+        wp = torch.empty(C, K, dtype=torch.bfloat16, device=dev)
+        wt = torch.empty(K, C, dtype=torch.bfloat16, device=dev) if x.requires_grad else None
+        out = torch.empty(n, C, dtype=torch.float32, device=dev)
+        desc = (ctypes.c_longlong * 8)(w.data_ptr(), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), C, K, K, 0, 0)
+        with torch.cuda.device(dev):
+            _launch("pcb_prep_weights_bf16", C * K, 1, desc)
+            _launch("pcb_gemm_nt_f32out_bf16", n * (K + 2 * C), x.data_ptr(), wp.data_ptr(), n, C, K, out.data_ptr())
+        ctx.save_for_backward(x, wt)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wt = ctx.saved_tensors
+        n, K = x.shape
+        C = ctx.wshape[0]
+        dev = x.device
+        gb = g.to(torch.bfloat16).contiguous()
+        lib = _lib.load()
+        dw = dx = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
+                ws = torch.empty(lib.pcb_gemm_tn_workspace(n, C, K), dtype=torch.float32, device=dev)
+                _launch("pcb_gemm_tn_bf16", 2 * n * (C + K), 0, gb.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
+                        0, 0, 0, n, C, K, ws.data_ptr(), dw.data_ptr(), 0, 0)
+            if ctx.needs_input_grad[0] and wt is not None:
+                dx = torch.empty(n, K, dtype=torch.bfloat16, device=dev)
+                _launch("pcb_gemm_nt_bf16", 2 * n * (C + K), 0, gb.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 0, 0, wt.data_ptr(), n, K,
+                        C, dx.data_ptr(), 0)
+        return dx, dw
+
+
+def point_linear(x, w):
+    """x [n, K] @ w[C, K]^T -> fp32 [n, C] with bf16 operands (K, C multiples of 8); see _PointLinear."""
+    return _PointLinear.apply(x.to(torch.bfloat16).contiguous(), w.contiguous())
+
+
+class _GatheredStack(torch.autograd.Function):
+    """A grouped stack whose FIRST layer is evaluated per point and gathered (csrc/gatherlin.hip):
+    y0[(s,j)] = u[idx[s,j]] + v[s] + wx (xyz[idx[s,j]] - ctr[s]) with per-point products u [B*N,C0],
+    v [B*S,C0] (fp32, from point_linear; v optional) and, optionally, the coordinate columns wx
+    [C0,3] of the first conv applied to the fp32 difference exactly as the reference forms it; then
+    BatchNorm + activation and the remaining layers / pooling exactly as _FusedStack.  Backward
+    returns du, dv, dwx; autograd takes du, dv on through the caller's point_linear calls.
+
+    Flat argument list: u, v, wx, xyz, ctr, idx, ns, act, pool, L, then per layer (weight, bias,
+    gamma, beta, running_mean, running_var, training, momentum, eps); layer 0's weight is None."""
+
+    NPER = 9
+    NHEAD = 10
+
+    @staticmethod
+    def forward(ctx, u, v, wx, xyz, ctr, idx, ns, act, pool, L, *flat):
         dev = u.device
         B, S = idx.shape[0], idx.shape[1]
         N = u.shape[0] // B
@@ -351,7 +402,10 @@ class _GatheredStack(torch.autograd.Function):
         nw = lib.pcb_mlp_stack_wbuf_elems(L, desc, 0, 0)
         wbuf = torch.empty(max(nw, 1), dtype=torch.bfloat16, device=dev)
         fdesc = (ctypes.c_double * (2 * L))(*[float(x) for t in layers for x in (t[7], t[8])])
-        gather = (ctypes.c_longlong * 8)(u.data_ptr(), v.data_ptr(), idx.data_ptr(), B, N, S, ns, 0)
+        gather = (ctypes.c_longlong * 12)(
+            u.data_ptr(), 0 if v is None else v.data_ptr(), idx.data_ptr(), B, N, S, ns,
+            0 if wx is None else xyz.data_ptr(), 0 if wx is None else ctr.data_ptr(),
+            0 if wx is None else wx.data_ptr(), 3, 0)
         C = widths[-1]
         if pool:
             out = torch.empty(R // pool, C, dtype=torch.bfloat16, device=dev)
@@ -363,21 +417,23 @@ class _GatheredStack(torch.autograd.Function):
             _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, 0, R, 0, 0, act, pool, 0, 1, gather,
                     wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
                     0 if arg is None else arg.data_ptr())
-        ctx.save_for_backward(idx, arg, ybuf, stz, wbuf, *[t[0] for t in layers[1:]])
-        ctx.cfg = (act, pool, L, ns, B, N, S, widths,
+        ctx.save_for_backward(idx, arg, ybuf, stz, wbuf, xyz if wx is not None else None,
+                              ctr if wx is not None else None, *[t[0] for t in layers[1:]])
+        ctx.cfg = (act, pool, L, ns, B, N, S, widths, v is not None, wx is not None,
                    [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
         return out
 
     @staticmethod
     def backward(ctx, g):
-        act, pool, L, ns, B, N, S, widths, flags = ctx.cfg
+        act, pool, L, ns, B, N, S, widths, has_v, has_wx, flags = ctx.cfg
         saved = ctx.saved_tensors
-        idx, arg, ybuf, stz, wbuf = saved[:5]
-        weights = [None] + list(saved[5:5 + L - 1])
+        idx, arg, ybuf, stz, wbuf, xyz, ctr = saved[:7]
+        weights = [None] + list(saved[7:7 + L - 1])
         dev = idx.device
         R = B * S * ns
         lib = _lib.load()
         g = g.float().contiguous() if pool else g.to(torch.bfloat16).contiguous()
+        H = _GatheredStack.NHEAD
         grads = [None] * (L * _GatheredStack.NPER)
         outs, ws_elems = [], 0
         for l in range(L):
@@ -385,7 +441,7 @@ class _GatheredStack(torch.autograd.Function):
             has_bias, has_affine, _ = flags[l]
             base = l * _GatheredStack.NPER
             dw = None
-            if l and ctx.needs_input_grad[7 + base]:
+            if l and ctx.needs_input_grad[H + base]:
                 dw = grads[base + 0] = torch.empty_like(weights[l])
                 ws_elems = max(ws_elems, lib.pcb_gemm_tn_workspace(R, C, widths[l - 1]))
             dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev) if has_bias else None
@@ -395,8 +451,12 @@ class _GatheredStack(torch.autograd.Function):
         layers = [(weights[l], None, None, None, None, None, flags[l][2]) for l in range(L)]
         desc = _stack_desc(layers, widths, ybuf, R, outs)
         du = torch.empty(B * N, widths[0], dtype=torch.float32, device=dev)   # zeroed by the library
-        dv = torch.empty(B * S, widths[0], dtype=torch.float32, device=dev)
-        gather = (ctypes.c_longlong * 8)(du.data_ptr(), dv.data_ptr(), idx.data_ptr(), B, N, S, ns, 0)
+        dv = torch.empty(B * S, widths[0], dtype=torch.float32, device=dev) if has_v else None
+        dwx = torch.empty(33, widths[0], 3, dtype=torch.float32, device=dev) if has_wx else None  # [0] = result
+        gather = (ctypes.c_longlong * 12)(
+            du.data_ptr(), 0 if dv is None else dv.data_ptr(), idx.data_ptr(), B, N, S, ns,
+            0 if dwx is None else xyz.data_ptr(), 0 if dwx is None else ctr.data_ptr(),
+            0 if dwx is None else dwx.data_ptr(), 3, 0)
         dzbuf = torch.empty(2 * R * max([8] + widths[:-1]), dtype=torch.bfloat16, device=dev) if L > 1 else None
         parts = torch.empty(max(_MAX_PARTS, 1024) * 2 * max(widths), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
@@ -404,14 +464,15 @@ class _GatheredStack(torch.autograd.Function):
             _launch("pcb_mlp_stack_backward", 0, L, desc, 0, g.data_ptr(), 0 if arg is None else arg.data_ptr(), R, 0,
                     0, act, pool, 0, gather, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), ws.data_ptr(),
                     0 if dzbuf is None else dzbuf.data_ptr(), 0)
-        return (du, dv, None, None, None, None, None, *grads)
+        return (du, dv, None if dwx is None else dwx[0], None, None, None, None, None, None, None, *grads)
 
 
-def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0):
+def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0, wx=None, xyz=None, ctr=None):
     """bf16 fused engine: the stack convs/bns applied to grouped rows whose first-layer products are
-    given per point: u [B*N, C0] fp32 (source points), v [B*S, C0] fp32 (centroids), idx [B,S,ns]
-    int64; row (s,j) of layer 0's output is u[idx[s,j]] + v[s].  convs[0] contributes only its bias
-    (its weight went into u, v).  Returns [B*S*ns, C] rows or, with pool = ns, [B*S, C]."""
+    given per point: u [B*N, C0] fp32 (source points), v [B*S, C0] fp32 (centroids) or None,
+    idx [B,S,ns] int64; row (s,j) of layer 0's output is u[idx[s,j]] + v[s] (+ wx (xyz_j - ctr_s)
+    with wx [C0,3] fp32, xyz [B,N,3], ctr [B,S,3]).  convs[0] contributes only its bias (its weight
+    went into u, v, wx).  Returns [B*S*ns, C] rows or, with pool = ns, [B*S, C]."""
     B, S, ns = idx.shape
     if pool not in (0, ns):
         raise ValueError("a gathered stack pools over its own neighbour axis")
@@ -429,7 +490,10 @@ def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0):
                  bn.running_mean if (track or not training) else None,
                  bn.running_var if (track or not training) else None,
                  training, momentum, bn.eps]
-    return _GatheredStack.apply(u.contiguous(), v.contiguous(), idx.contiguous(), ns, act, pool, len(convs), *flat)
+    return _GatheredStack.apply(u.contiguous(), None if v is None else v.contiguous(),
+                                None if wx is None else wx.contiguous(),
+                                None if wx is None else xyz.contiguous(), None if wx is None else ctr.contiguous(),
+                                idx.contiguous(), ns, act, pool, len(convs), *flat)
 
 
 _GATHERED = True
