@@ -924,8 +924,12 @@ extern "C" int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)nt_grid_x(PRO_PLAIN, R, N), ny);
     const RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0, 1>), grid, dim3(256), 0, (hipStream_t)stream, A, (const u16 *)w, R, N,
-                       K, (u16 *)out, (float *)nullptr, none);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
+    hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0, 1>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out,
+                       (float *)nullptr, none);
+    pcb_timer_end(st, timed, 2.0 * R * K + 4.0 * R * N, 20, R, N, K);
     return pcb_check_launch();
 }
 

@@ -469,3 +469,69 @@ def test_gathered_first_layer_matches_grouped_rows(rm, kind):
     for n in ref:
         eg, er = _rel(gath[n], ref[n]), _rel(grp[n], ref[n])
         assert eg <= max(1.6 * er, 3e-2), (n, eg, er)
+
+
+@pytest.mark.parametrize("pooled,with_v,with_wx", [(0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1)])
+def test_gather_add_and_scatter_dy_entry_points(rm, pooled, with_v, with_wx):
+    """pcb_gather_add_bf16 / pcb_scatter_dy_bf16 against a direct PyTorch evaluation of their
+    definitions (include/pcb_hip.h): rows, BatchNorm statistics slabs, du / dv / dWx."""
+    import ctypes
+    from pointcloud_bridge_amd import _lib
+    from pointcloud_bridge_amd.ops import _launch
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(21)
+    B, N, S, ns, C = 2, 96, 40, 8, 64
+    R = B * S * ns
+    u = torch.randn(B * N, C, generator=g).to(dev)
+    v = torch.randn(B * S, C, generator=g).to(dev) if with_v else None
+    wx = torch.randn(C, 3, generator=g).to(dev) if with_wx else None
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    ctr = torch.rand(B, S, 3, generator=g).to(dev)
+    idx = torch.randint(0, N, (B, S, ns), generator=g).to(dev)
+    idx[:, :, ns // 2:] = idx[:, :, :1]  # padded tail, as ball query produces it
+    lib = _lib.load()
+    npart = lib.pcb_gather_add_partials(R, C)
+    y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+    slabs = torch.empty(npart, 2, C, device=dev)
+    _launch("pcb_gather_add_bf16", 0, u.data_ptr(), 0 if v is None else v.data_ptr(), idx.data_ptr(), B, N, S, ns, C,
+            xyz.data_ptr(), ctr.data_ptr(), 0 if wx is None else wx.data_ptr(), 3, y.data_ptr(), slabs.data_ptr())
+    src = (idx + torch.arange(B, device=dev).view(B, 1, 1) * N).reshape(-1)
+    grp = torch.arange(B * S, device=dev).repeat_interleave(ns)
+    ref = u[src]
+    if with_v:
+        ref = ref + v[grp]
+    diff = xyz.reshape(-1, 3)[src] - ctr.reshape(-1, 3)[grp]
+    if with_wx:
+        ref = ref + diff @ wx.t()
+    assert torch.allclose(y.float(), ref.to(torch.bfloat16).float(), rtol=0, atol=2 ** -7 * float(ref.abs().max()))
+    yf = y.float()
+    assert torch.allclose(slabs[:, 0].sum(0), yf.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(slabs[:, 1].sum(0), (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+
+    # backward: dy = scale*dz*act'(y*scale+shift) + p*y + q   (ReLU)
+    scale, shift = torch.rand(C, generator=g).to(dev) + 0.5, torch.randn(C, generator=g).to(dev) * 0.3
+    p, q = torch.randn(C, generator=g).to(dev) * 0.1, torch.randn(C, generator=g).to(dev) * 0.1
+    if pooled:
+        dout = torch.randn(B * S, C, generator=g).to(dev)
+        arg = torch.randint(0, ns, (B * S, C), generator=g).to(dev).to(torch.uint8)
+        dzf = torch.zeros(B * S, ns, C, device=dev)
+        dzf.scatter_(1, arg.long().unsqueeze(1), dout.unsqueeze(1))
+        dzf = dzf.view(R, C)
+        dz = None
+    else:
+        dz = torch.randn(R, C, generator=g).to(dev).to(torch.bfloat16)
+        dzf, dout, arg = dz.float(), None, None
+    dy = scale * dzf * ((yf * scale + shift) > 0).float() + p * yf + q
+    du = torch.zeros(B * N, C, device=dev)
+    dv = torch.empty(B * S, C, device=dev)
+    dwx = torch.zeros(33, C, 3, device=dev) if with_wx else None
+    _launch("pcb_scatter_dy_bf16", 0, pooled, 0 if dz is None else dz.data_ptr(), y.data_ptr(), scale.data_ptr(),
+            shift.data_ptr(), p.data_ptr(), q.data_ptr(), 0 if dout is None else dout.data_ptr(),
+            0 if arg is None else arg.data_ptr(), 1, idx.data_ptr(), B, N, S, ns, C, xyz.data_ptr(), ctr.data_ptr(),
+            du.data_ptr(), dv.data_ptr(), 0 if dwx is None else dwx.data_ptr())
+    du_ref = torch.zeros(B * N, C, device=dev).index_add_(0, src, dy)
+    dv_ref = dy.view(B * S, ns, C).sum(1)
+    assert torch.allclose(du, du_ref, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(dv, dv_ref, rtol=1e-4, atol=1e-4)
+    if with_wx:
+        assert torch.allclose(dwx[0], dy.t() @ diff, rtol=1e-4, atol=1e-3)
