@@ -143,9 +143,10 @@ int pcb_interpolate_bwd(const float *grad_out, const float *w, const int64_t *id
  *   out_idx [B,N,k] int64, nearest first (slot 0 is the point itself on duplicate-free data)
  * pd(i,j) = (|xi|^2 + (-2*<xi,xj>)) + |xj|^2 with <,> an fma chain in channel order and |x|^2 a
  * left-to-right sum of squares; the k smallest pd, ties by lower index.
+ * norms [B,N] fp32: caller-owned scratch (receives |x|^2 of every point from a pre-pass).
  * Requires 1 <= k <= 32, k <= N, 1 <= D <= 128.
  */
-int pcb_knn(const float *x, int B, int N, int D, int k, int64_t *out_idx, void *stream);
+int pcb_knn(const float *x, int B, int N, int D, int k, float *norms, int64_t *out_idx, void *stream);
 
 /*
  * EdgeConv edge features.  Replaces the gather/repeat/cat of DGCNN.get_graph_feature,

@@ -19,6 +19,10 @@
 //   per-lane queue in LDS -- a predicated store -- and the wave drains all queues together when one
 //   runs full: the j-th queued entries of all lanes are inserted in the same pass.
 //   lanes n and n+32 merge their lists at the end (ties: lower index first)
+//   The candidate stages are double-buffered: the next stage's rows are in flight (registers) while
+//   the MFMAs of the current one run, one barrier per stage.  |x_j|^2 comes from a small pre-pass
+//   (knn_norms_kernel: one lane per point, the same left-to-right sum the reference's
+//   torch.sum(x**2) chain is pinned to) instead of 64 lanes recomputing it per stage.
 #include "pcb_common.h"
 
 namespace {
@@ -70,18 +74,35 @@ __device__ __forceinline__ void insert_sorted_by_index(float (&bd)[K], int (&bi)
     bi[0] = hi ? cand : bi[0];
 }
 
+// |x|^2 of every point: left-to-right sum of squares, multiply and add rounded separately.
+__global__ __launch_bounds__(kThreads) void knn_norms_kernel(const float *__restrict__ x, long rows, int D,
+                                                              float *__restrict__ norms)
+{
+    const long r = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    const float *__restrict__ p = x + r * D;
+    float s = 0.0f;
+    for (int c = 0; c < D; ++c) {
+        const float v = p[c];
+        s = c ? __fadd_rn(s, __fmul_rn(v, v)) : __fmul_rn(v, v);
+    }
+    norms[r] = s;
+}
+
 // DP = D rounded up to a power of two >= 4; channels D..DP-1 are zero padding, which changes no
 // rounding step of the chain (fma(0, 0, acc) == acc) nor of the norms (s + 0*0 == s).
 template <int DP, int K>
-__global__ __launch_bounds__(kThreads) void knn_mfma_kernel(const float *__restrict__ x, int N, int D,
+__global__ __launch_bounds__(kThreads) void knn_mfma_kernel(const float *__restrict__ x,
+                                                             const float *__restrict__ norms, int N, int D,
                                                              int k, int64_t *__restrict__ out)
 {
     constexpr int S = DP / 2;         // MFMA steps per tile (two channels each)
     constexpr int LD = DP + 4;        // LDS row stride in floats: rows 16 B apart in bank space
     constexpr int kTC = DP <= 32 ? 128 : (DP <= 64 ? 64 : 32);  // candidates per LDS stage (<= 17.4 KB)
     constexpr int QCAP = 20;          // queue slots per lane; drained when a lane has > QCAP - 16
-    __shared__ __attribute__((aligned(16))) float tile[kTC * LD];  // row m: [h][s] = x[m][2s+h]
-    __shared__ __attribute__((aligned(16))) float cnrm[kTC];
+    constexpr int NPT = kTC * DP / kThreads;  // staged elements per thread and stage
+    __shared__ __attribute__((aligned(16))) float tiles[2][kTC * LD];  // row m: [h][s] = x[m][2s+h]
+    __shared__ __attribute__((aligned(16))) float cnrms[2][kTC];
     __shared__ float qd[QCAP][kThreads];  // [slot][thread]: a lane's slots are a bank-conflict-free column
     __shared__ int qi[QCAP][kThreads];
 
@@ -99,11 +120,7 @@ __global__ __launch_bounds__(kThreads) void knn_mfma_kernel(const float *__restr
     float q[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) q[s] = (2 * s + h) < D ? xq[2 * s + h] : 0.0f;
-    float qnorm = 0.0f;  // |x|^2 = left-to-right sum of squares over ALL channels
-    for (int c = 0; c < D; ++c) {
-        const float v = xq[c];
-        qnorm = c ? __fadd_rn(qnorm, __fmul_rn(v, v)) : __fmul_rn(v, v);
-    }
+    const float qnorm = norms[(size_t)b * N + (qvalid ? qn_idx : N - 1)];
 
     float bd[K];
     int bi[K];
@@ -126,25 +143,38 @@ __global__ __launch_bounds__(kThreads) void knn_mfma_kernel(const float *__restr
         qcnt = 0;
     };
 
-    for (int base = 0; base < N; base += kTC) {
-        __syncthreads();
-        // stage 128 candidate rows, channels de-interleaved into [evens | odds]
-        for (int e = t; e < kTC * DP; e += kThreads) {
+    // stage = kTC candidate rows, channels de-interleaved into [evens | odds]; a thread's NPT
+    // elements are e = t + i*256 (consecutive lanes -> consecutive channels of a row: coalesced)
+    float pre[NPT];
+    float pre_n = 0.0f;
+    auto fetch = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int e = t + i * kThreads;
             const int m = e / DP, c = e % DP;
             const int row = base + m;
-            const float v = (row < N && c < D) ? xb[(size_t)row * D + c] : 0.0f;
-            tile[m * LD + (c & 1) * S + (c >> 1)] = v;
+            pre[i] = (row < N && c < D) ? xb[(size_t)row * D + c] : 0.0f;
         }
-        __syncthreads();
-        if (t < kTC) {
-            float s = 0.0f;
-            for (int c = 0; c < DP; ++c) {
-                const float v = tile[t * LD + (c & 1) * S + (c >> 1)];
-                s = c ? __fadd_rn(s, __fmul_rn(v, v)) : __fmul_rn(v, v);
-            }
-            cnrm[t] = s;
+        if (t < kTC) pre_n = base + t < N ? norms[(size_t)b * N + base + t] : 0.0f;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int e = t + i * kThreads;
+            const int m = e / DP, c = e % DP;
+            tiles[buf][m * LD + (c & 1) * S + (c >> 1)] = pre[i];
         }
-        __syncthreads();
+        if (t < kTC) cnrms[buf][t] = pre_n;
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int base = 0; base < N; base += kTC, buf ^= 1) {
+        const bool more = base + kTC < N;
+        if (more) fetch(base + kTC);  // in flight under this stage's MFMAs
+        const float *const tile = tiles[buf];
+        const float *const cnrm = cnrms[buf];
 
 #pragma unroll 1
         for (int tt = 0; tt < kTC / 32; ++tt) {
@@ -192,6 +222,8 @@ __global__ __launch_bounds__(kThreads) void knn_mfma_kernel(const float *__restr
             }
             if (__any(qcnt > QCAP - 16)) drain();
         }
+        if (more) stash(buf ^ 1);  // the other buffer was last read one barrier ago
+        __syncthreads();
     }
     drain();
 
@@ -211,30 +243,33 @@ __global__ __launch_bounds__(kThreads) void knn_mfma_kernel(const float *__restr
 }
 
 template <int DP>
-int launch_knn(const float *x, int B, int N, int D, int k, int64_t *out, hipStream_t st)
+int launch_knn(const float *x, float *norms, int B, int N, int D, int k, int64_t *out, hipStream_t st)
 {
+    const long rows = (long)B * N;
+    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, x,
+                       rows, D, norms);
     const dim3 grid((N + 127) / 128, B);
     if (k <= 8)
-        hipLaunchKernelGGL((knn_mfma_kernel<DP, 8>), grid, dim3(kThreads), 0, st, x, N, D, k, out);
+        hipLaunchKernelGGL((knn_mfma_kernel<DP, 8>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out);
     else if (k <= 20)
-        hipLaunchKernelGGL((knn_mfma_kernel<DP, 20>), grid, dim3(kThreads), 0, st, x, N, D, k, out);
+        hipLaunchKernelGGL((knn_mfma_kernel<DP, 20>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out);
     else
-        hipLaunchKernelGGL((knn_mfma_kernel<DP, 32>), grid, dim3(kThreads), 0, st, x, N, D, k, out);
+        hipLaunchKernelGGL((knn_mfma_kernel<DP, 32>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out);
     return pcb_check_launch();
 }
 
 }  // namespace
 
-extern "C" int pcb_knn(const float *x, int B, int N, int D, int k, int64_t *out_idx, void *stream)
+extern "C" int pcb_knn(const float *x, int B, int N, int D, int k, float *norms, int64_t *out_idx, void *stream)
 {
-    if (!x || !out_idx || B <= 0 || N <= 0 || D <= 0) return PCB_ERR_INVALID_ARG;
+    if (!x || !norms || !out_idx || B <= 0 || N <= 0 || D <= 0) return PCB_ERR_INVALID_ARG;
     if (k < 1 || k > 32 || k > N) return PCB_ERR_INVALID_ARG;
     if (D > 128) return PCB_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (D <= 4) return launch_knn<4>(x, B, N, D, k, out_idx, st);
-    if (D <= 8) return launch_knn<8>(x, B, N, D, k, out_idx, st);
-    if (D <= 16) return launch_knn<16>(x, B, N, D, k, out_idx, st);
-    if (D <= 32) return launch_knn<32>(x, B, N, D, k, out_idx, st);
-    if (D <= 64) return launch_knn<64>(x, B, N, D, k, out_idx, st);
-    return launch_knn<128>(x, B, N, D, k, out_idx, st);
+    if (D <= 4) return launch_knn<4>(x, norms, B, N, D, k, out_idx, st);
+    if (D <= 8) return launch_knn<8>(x, norms, B, N, D, k, out_idx, st);
+    if (D <= 16) return launch_knn<16>(x, norms, B, N, D, k, out_idx, st);
+    if (D <= 32) return launch_knn<32>(x, norms, B, N, D, k, out_idx, st);
+    if (D <= 64) return launch_knn<64>(x, norms, B, N, D, k, out_idx, st);
+    return launch_knn<128>(x, norms, B, N, D, k, out_idx, st);
 }

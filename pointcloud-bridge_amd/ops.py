@@ -194,8 +194,9 @@ def knn(x_bnd, k):
     if not 1 <= k <= 32 or D > 128:
         raise ValueError(f"knn supports 1 <= k <= 32 and D <= 128 (k={k}, D={D})")
     out = torch.empty(B, N, k, dtype=torch.int64, device=x.device)
+    norms = torch.empty(B, N, dtype=torch.float32, device=x.device)  # |x|^2 scratch of the kernel
     with torch.cuda.device(x.device):
-        _launch("pcb_knn", B * N * N, x.data_ptr(), B, N, D, k, out.data_ptr())
+        _launch("pcb_knn", B * N * N, x.data_ptr(), B, N, D, k, norms.data_ptr(), out.data_ptr())
     return out
 
 

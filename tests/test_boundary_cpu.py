@@ -45,8 +45,8 @@ def test_argument_validation_without_gpu(lib):
     L = lib.load()
     assert L.pcb_fps(None, 1, 8, 4, None, None, None) == -1
     assert L.pcb_ball_query(None, None, 1, 8, 4, 0.1, 4, None, None) == -1
-    assert L.pcb_knn(ctypes.c_void_p(8), 1, 8, 3, 99, ctypes.c_void_p(8), None) == -1      # k > 32
-    assert L.pcb_knn(ctypes.c_void_p(8), 1, 64, 400, 4, ctypes.c_void_p(8), None) == -2    # D > 128
+    assert L.pcb_knn(ctypes.c_void_p(8), 1, 8, 3, 99, ctypes.c_void_p(8), ctypes.c_void_p(8), None) == -1      # k > 32
+    assert L.pcb_knn(ctypes.c_void_p(8), 1, 64, 400, 4, ctypes.c_void_p(8), ctypes.c_void_p(8), None) == -2    # D > 128
     assert L.pcb_three_nn(ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 8, 2, 3, ctypes.c_void_p(8),
                           ctypes.c_void_p(8), None) == -1                                    # S < k
     with pytest.raises(lib.PcbError):
