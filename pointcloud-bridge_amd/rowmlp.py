@@ -728,11 +728,60 @@ def interpolate_concat(skip_rows, feat_bsc, d2, idx):
     return rows, (-d1 if d1 % 8 else 0)
 
 
+class _BNActRows(torch.autograd.Function):
+    """act(BatchNorm(y)) on bf16 rows [R,C] with no GEMM in front (DGCNN.local_bn): one statistics
+    pass, the finalize kernel, one apply pass; backward = one reduce + one apply pass (csrc/rowbn.hip)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, act):
+        R, C = y.shape
+        dev = y.device
+        stats = torch.zeros(6, C, dtype=torch.float32, device=dev)  # sums(2) | scale | shift | mean | invstd
+        out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            if training:
+                _launch("pcb_colstats_bf16", R * C, y.data_ptr(), R, C, stats[0:2].data_ptr())
+            _launch("pcb_bn_finalize", C, stats[0:2].data_ptr(), 1, R, 0, C,
+                    0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(), 0,
+                    0 if running_mean is None else running_mean.data_ptr(),
+                    0 if running_var is None else running_var.data_ptr(),
+                    float(momentum), float(eps), int(training), stats[2].data_ptr(), stats[3].data_ptr(),
+                    stats[4].data_ptr(), stats[5].data_ptr())
+            _launch("pcb_bn_act_bf16", R * C, y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), R, C, act,
+                    out.data_ptr())
+        ctx.save_for_backward(y, stats)
+        ctx.cfg = (int(training), act, gamma is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, stats = ctx.saved_tensors
+        training, act, has_affine = ctx.cfg
+        R, C = y.shape
+        dev = y.device
+        bsums = torch.zeros(2, C, dtype=torch.float32, device=dev)
+        dy = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+        gb = g.to(torch.bfloat16).contiguous()
+        with torch.cuda.device(dev):
+            _launch("pcb_bn_act_bwd_bf16", R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                    stats[4].data_ptr(), stats[5].data_ptr(), R, C, act, training, bsums.data_ptr(), dy.data_ptr())
+        return (dy, bsums[1].clone() if has_affine else None, bsums[0].clone() if has_affine else None,
+                None, None, None, None, None, None)
+
+
 def bn_act_rows(bn, x, act=ACT_NONE):
     """BatchNorm (+ activation) on rows without a preceding conv (DGCNN.local_bn)."""
     if not is_bf16():
         return _act_torch(_bn_rows_fp32(bn, x), act)
-    return _act_torch(_bn_rows_fp32(bn, x.float()), act).to(torch.bfloat16)
+    if isinstance(bn, nn.SyncBatchNorm) or x.shape[1] % 8 != 0 or _ENGINE != "fused":
+        return _act_torch(_bn_rows_fp32(bn, x.float()), act).to(torch.bfloat16)
+    momentum = _bn_bookkeeping(bn)
+    training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    track = bn.track_running_stats and bn.running_mean is not None
+    return _BNActRows.apply(x.to(torch.bfloat16).contiguous(), bn.weight, bn.bias,
+                            bn.running_mean if (track or not training) else None,
+                            bn.running_var if (track or not training) else None,
+                            training, momentum, bn.eps, act)
 
 
 def mlp_rows(convs, bns, x, act=ACT_RELU, pool=0, perm=0):
