@@ -203,6 +203,35 @@ int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, Lay
 }
 
 inline float *row(float *stz, const Layer &a, int r) { return stz + a.st_off + (long)r * a.C; }
+
+// A second stream for the weight-gradient GEMMs of a stack's backward pass: dW is needed by nobody
+// before the optimizer, so gemm_tn(l) runs beside gemm_nt(l) (the input gradient, which IS on the
+// critical path).  Both are bandwidth kernels that leave latency bubbles when alone on the chip.
+// Fork/join with events; the join at the end of every backward call keeps the caller's
+// stream-ordered view of all buffers intact.  PCB_WGRAD_STREAM=0 turns it off.
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t ring[64] = {};
+    unsigned next = 0;
+    bool failed = false;
+    hipEvent_t event()
+    {
+        hipEvent_t &e = ring[next++ & 63];
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        return e;
+    }
+};
+SideStream *side_stream()
+{
+    static const bool enabled = !(getenv("PCB_WGRAD_STREAM") && atoi(getenv("PCB_WGRAD_STREAM")) == 0);
+    if (!enabled) return nullptr;
+    static SideStream per_device[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream &s = per_device[dev];
+    if (!s.st && !s.failed && hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) s.failed = true;
+    return s.failed ? nullptr : &s;
+}
 }  // namespace
 
 #define PCB_TRY(expr)                \
@@ -346,70 +375,91 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
     for (int l = 0; l + 1 < L; ++l) maxw = ly[l].C > maxw ? ly[l].C : maxw;
     if (L > 1 && !dzbuf) return PCB_ERR_INVALID_ARG;
 
+    hipStream_t main_st = (hipStream_t)stream;
+    SideStream *side = side_stream();
+    hipEvent_t tn_done = nullptr;  // completion of the most recent gemm_tn on the side stream
     const void *dz = pool ? nullptr : g;                 // dense upstream gradient (bf16 rows)
     const float *dout = pool ? (const float *)g : nullptr;  // pooled upstream gradient (fp32)
     bool have_parts = false;  // sums of layer l already accumulated by the dgrad GEMM of layer l+1
     int have_nparts = 0;
-    for (int l = L - 1; l >= 0; --l) {
-        const Layer &a = ly[l];
-        const bool pooled = pool && l == L - 1;
-        float *scale = row(stz, a, 2), *shift = row(stz, a, 3), *mean = row(stz, a, 4), *invstd = row(stz, a, 5);
-        float *bsums = row(stz, a, 6), *p = row(stz, a, 8), *q = row(stz, a, 9);
-        float *sums = bsums;
-        int nparts = 1;
-        if (have_parts) {
-            sums = parts;
-            nparts = have_nparts;
-        } else if (pooled) {
-            PCB_TRY(pcb_bn_act_max_bwd_reduce_bf16(dout, argmax, a.y, scale, shift, mean, invstd, R / pool, pool, a.C,
-                                                   act, bsums, stream));
-        } else {
-            PCB_TRY(pcb_bn_act_bwd_reduce_bf16(dz, a.y, scale, shift, mean, invstd, R, a.C, act, bsums, stream));
-        }
-        PCB_TRY(pcb_bn_bwd_finalize(sums, nparts, R, a.C, scale, mean, invstd, a.training, p, q, a.dgamma, a.dbeta,
-                                    a.dbias, stream));
-        have_parts = false;
-        const int apro = pooled ? 3 : 2;
-        const int ns = pooled ? pool : 1;
-        if (gathered && l == 0) {
-            // gathered layer: its input gradients are du (per source point) and dv (per centroid)
-            if (pooled && pool != ga.ns) return PCB_ERR_INVALID_ARG;
-            if (hipMemsetAsync(ga.u, 0, sizeof(float) * (size_t)ga.B * ga.N * a.C, (hipStream_t)stream) != hipSuccess)
-                return PCB_ERR_LAUNCH;
-            if (ga.wx && hipMemsetAsync(ga.wx, 0, sizeof(float) * 3 * a.C * 33, (hipStream_t)stream) != hipSuccess)
-                return PCB_ERR_LAUNCH;
-            PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx, ga.B,
-                                        ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.u, ga.v, ga.wx, stream));
-            break;
-        }
-        // weight gradient, in the parameter's own layout
-        if (a.dW) {
-            if (l) {
-                const Layer &b = ly[l - 1];
-                PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 1, b.y, row(stz, b, 2),
-                                         row(stz, b, 3), act, R, a.C, a.kp, workspace, a.dW, a.k, 0, stream));
+    auto layers = [&]() -> int {
+        for (int l = L - 1; l >= 0; --l) {
+            const Layer &a = ly[l];
+            const bool pooled = pool && l == L - 1;
+            float *scale = row(stz, a, 2), *shift = row(stz, a, 3), *mean = row(stz, a, 4), *invstd = row(stz, a, 5);
+            float *bsums = row(stz, a, 6), *p = row(stz, a, 8), *q = row(stz, a, 9);
+            float *sums = bsums;
+            int nparts = 1;
+            if (have_parts) {
+                sums = parts;
+                nparts = have_nparts;
+            } else if (pooled) {
+                PCB_TRY(pcb_bn_act_max_bwd_reduce_bf16(dout, argmax, a.y, scale, shift, mean, invstd, R / pool, pool,
+                                                       a.C, act, bsums, stream));
             } else {
-                PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 0, x, nullptr, nullptr,
-                                         0, R, a.C, a.kp, workspace, a.dW, a.k, perm, stream));
+                PCB_TRY(pcb_bn_act_bwd_reduce_bf16(dz, a.y, scale, shift, mean, invstd, R, a.C, act, bsums, stream));
             }
+            PCB_TRY(pcb_bn_bwd_finalize(sums, nparts, R, a.C, scale, mean, invstd, a.training, p, q, a.dgamma, a.dbeta,
+                                        a.dbias, stream));
+            have_parts = false;
+            const int apro = pooled ? 3 : 2;
+            const int ns = pooled ? pool : 1;
+            if (gathered && l == 0) {
+                // gathered layer: its input gradients are du (per source point) and dv (per centroid)
+                if (pooled && pool != ga.ns) return PCB_ERR_INVALID_ARG;
+                if (hipMemsetAsync(ga.u, 0, sizeof(float) * (size_t)ga.B * ga.N * a.C, main_st) != hipSuccess)
+                    return PCB_ERR_LAUNCH;
+                if (ga.wx && hipMemsetAsync(ga.wx, 0, sizeof(float) * 3 * a.C * 33, main_st) != hipSuccess)
+                    return PCB_ERR_LAUNCH;
+                PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx,
+                                            ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.u, ga.v, ga.wx, stream));
+                return PCB_OK;
+            }
+            // weight gradient, in the parameter's own layout -- on the side stream
+            hipEvent_t tn_prev = tn_done;  // gemm_tn(l+1): still reading the buffer gemm_nt(l) will write
+            if (a.dW) {
+                void *tn_stream = stream;
+                hipEvent_t fork = side ? side->event() : nullptr;
+                if (fork && hipEventRecord(fork, main_st) == hipSuccess &&
+                    hipStreamWaitEvent(side->st, fork, 0) == hipSuccess)
+                    tn_stream = side->st;
+                if (l) {
+                    const Layer &b = ly[l - 1];
+                    PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 1, b.y,
+                                             row(stz, b, 2), row(stz, b, 3), act, R, a.C, a.kp, workspace, a.dW, a.k, 0,
+                                             tn_stream));
+                } else {
+                    PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 0, x, nullptr,
+                                             nullptr, 0, R, a.C, a.kp, workspace, a.dW, a.k, perm, tn_stream));
+                }
+                if (tn_stream != stream) {
+                    tn_done = side->event();
+                    if (!tn_done || hipEventRecord(tn_done, side->st) != hipSuccess) return PCB_ERR_LAUNCH;
+                }
+            }
+            // input gradient
+            if (l == 0 && !dx) return PCB_OK;
+            if (tn_prev && hipStreamWaitEvent(main_st, tn_prev, 0) != hipSuccess) return PCB_ERR_LAUNCH;
+            void *dprev = l ? (void *)((unsigned short *)dzbuf + (long)(l & 1) * R * maxw) : dx;
+            const unsigned short *wt = wb + a.wt_off;
+            if (l && a.kp <= 128 && parts) {
+                const Layer &b = ly[l - 1];
+                PCB_TRY(pcb_gemm_nt_red_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C,
+                                             dprev, b.y, row(stz, b, 2), row(stz, b, 3), row(stz, b, 4), row(stz, b, 5),
+                                             act, parts, stream));
+                have_parts = true;
+                have_nparts = pcb_gemm_nt_partials(apro, R, a.kp);
+            } else {
+                PCB_TRY(pcb_gemm_nt_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C,
+                                         dprev, nullptr, stream));
+            }
+            dz = dprev;
+            dout = nullptr;
         }
-        // input gradient
-        if (l == 0 && !dx) break;
-        void *dprev = l ? (void *)((unsigned short *)dzbuf + (long)(l & 1) * R * maxw) : dx;
-        const unsigned short *wt = wb + a.wt_off;
-        if (l && a.kp <= 128 && parts) {
-            const Layer &b = ly[l - 1];
-            PCB_TRY(pcb_gemm_nt_red_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C, dprev,
-                                         b.y, row(stz, b, 2), row(stz, b, 3), row(stz, b, 4), row(stz, b, 5), act, parts,
-                                         stream));
-            have_parts = true;
-            have_nparts = pcb_gemm_nt_partials(apro, R, a.kp);
-        } else {
-            PCB_TRY(pcb_gemm_nt_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C, dprev,
-                                     nullptr, stream));
-        }
-        dz = dprev;
-        dout = nullptr;
-    }
-    return PCB_OK;
+        return PCB_OK;
+    };
+    const int status = layers();
+    // join: everything the side stream did is ordered before whatever the caller enqueues next
+    if (tn_done && hipStreamWaitEvent(main_st, tn_done, 0) != hipSuccess) return PCB_ERR_LAUNCH;
+    return status;
 }
