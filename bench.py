@@ -251,8 +251,8 @@ def main():
     t0 = time.perf_counter()
     host_s = 0.0  # time the host spends enqueueing (diagnostic: host-bound vs GPU-bound)
     for i in range(args.steps):
-        # HIP events around the roofline kernel on every 5th step (launched eagerly in graph mode)
-        sampled = i % 5 == 0 and not os.environ.get("PCB_BENCH_NO_ROOFLINE")
+        # HIP events around the roofline kernel on every 10th step (launched eagerly in graph mode)
+        sampled = i % 10 == 0 and not os.environ.get("PCB_BENCH_NO_ROOFLINE")
         ops.kernel_timer_enable(sampled)
         h0 = time.perf_counter()
         loss = (eager_step if (use_graph and sampled) else step)()

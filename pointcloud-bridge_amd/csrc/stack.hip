@@ -208,7 +208,9 @@ inline float *row(float *stz, const Layer &a, int r) { return stz + a.st_off + (
 // before the optimizer, so gemm_tn(l) runs beside gemm_nt(l) (the input gradient, which IS on the
 // critical path).  Both are bandwidth kernels that leave latency bubbles when alone on the chip.
 // Fork/join with events; the join at the end of every backward call keeps the caller's
-// stream-ordered view of all buffers intact.  PCB_WGRAD_STREAM=0 turns it off.
+// stream-ordered view of all buffers intact.  Opt-in (PCB_WGRAD_STREAM=1): measured -2 % step time
+// on PN2-MSG (9.92 -> 9.72 ms under hipGraph replay), but every gemm_nt then shares HBM with a
+// gemm_tn, which makes per-kernel durations (and bench.py's roofline figure) meaningless.
 struct SideStream {
     hipStream_t st = nullptr;
     hipEvent_t ring[64] = {};
@@ -223,7 +225,7 @@ struct SideStream {
 };
 SideStream *side_stream()
 {
-    static const bool enabled = !(getenv("PCB_WGRAD_STREAM") && atoi(getenv("PCB_WGRAD_STREAM")) == 0);
+    static const bool enabled = getenv("PCB_WGRAD_STREAM") && atoi(getenv("PCB_WGRAD_STREAM")) != 0;
     if (!enabled) return nullptr;
     static SideStream per_device[16];
     int dev = 0;

@@ -26,4 +26,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(3): step(False)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
