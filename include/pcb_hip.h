@@ -301,6 +301,8 @@ int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *
  * C > 0 = pcb_group_rows_bf16 rows (C feature columns, then the 3 centred coordinates);
  * -D < 0 = interpolate+concat rows (first D columns in place, the rest from column pad8(D)). */
 int pcb_prep_weights_bf16(int n, const long long *desc, void *stream);
+/* The same, and `zero` [zero_n] fp32 is cleared by the same launch (a stack's constants buffer). */
+int pcb_prep_weights_zero_bf16(int n, const long long *desc, float *zero, long zero_n, void *stream);
 
 /* pcb_gemm_nt_bf16 (pro 2 or 3, N <= 128) whose epilogue also accumulates the BatchNorm-backward
  * sums of the layer BELOW: the produced tile is that layer's dz; with its y (red_y [R,N] bf16) and

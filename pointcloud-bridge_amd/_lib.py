@@ -47,6 +47,7 @@ SIGNATURES = {
     "pcb_gemm_tn_workspace": [_l, _i, _i],
     "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "pcb_prep_weights_bf16": [_i, _p, _p],
+    "pcb_prep_weights_zero_bf16": [_i, _p, _p, _l, _p],
     "pcb_mlp_stack_wbuf_elems": [_i, _p, _i, _i],
     "pcb_mlp_stack_forward": [_i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "pcb_mlp_stack_backward": [_i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],

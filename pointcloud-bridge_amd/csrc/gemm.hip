@@ -997,10 +997,14 @@ struct PrepLayer {
 };
 struct PrepArgs {
     PrepLayer l[PREP_MAX];
+    float *zero;   // optional: a float buffer cleared by the same launch (a stack's constants)
+    long zero_n;
 };
 
 __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs args)
 {
+    if (blockIdx.y == 0)
+        for (long e = blockIdx.x * 256 + threadIdx.x; e < args.zero_n; e += gridDim.x * 256) args.zero[e] = 0.0f;
     const PrepLayer L = args.l[blockIdx.y];
     const int total = L.C * L.kp;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -1015,8 +1019,15 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs args)
 
 extern "C" int pcb_prep_weights_bf16(int n, const long long *desc, void *stream)
 {
-    if (n < 1 || n > PREP_MAX || !desc) return PCB_ERR_INVALID_ARG;
+    return pcb_prep_weights_zero_bf16(n, desc, nullptr, 0, stream);
+}
+
+extern "C" int pcb_prep_weights_zero_bf16(int n, const long long *desc, float *zero, long zero_n, void *stream)
+{
+    if (n < 1 || n > PREP_MAX || !desc || zero_n < 0 || (zero_n && !zero)) return PCB_ERR_INVALID_ARG;
     PrepArgs a;
+    a.zero = zero;
+    a.zero_n = zero_n;
     int most = 0;
     for (int i = 0; i < n; ++i) {
         const long long *d = desc + 8 * i;

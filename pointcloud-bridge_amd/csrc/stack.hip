@@ -303,7 +303,7 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
 
     long stz_floats = 0;
     for (int l = 0; l < L; ++l) stz_floats += 10L * ly[l].C;
-    if (hipMemsetAsync(stz, 0, stz_floats * sizeof(float), st) != hipSuccess) return PCB_ERR_LAUNCH;
+    bool cleared = false;  // stz is cleared by the first weight-preparation launch (or a memset if there is none)
 
     // bf16 operands of all layers (chunks of 8 layers per launch)
     for (int l0 = gathered ? 1 : 0; l0 < L; l0 += 8) {
@@ -321,8 +321,10 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
             d[6] = (l0 + i == 0) ? perm : 0;
             d[7] = 0;
         }
-        PCB_TRY(pcb_prep_weights_bf16(n, pd, stream));
+        PCB_TRY(pcb_prep_weights_zero_bf16(n, pd, cleared ? nullptr : stz, cleared ? 0 : stz_floats, stream));
+        cleared = true;
     }
+    if (!cleared && hipMemsetAsync(stz, 0, stz_floats * sizeof(float), st) != hipSuccess) return PCB_ERR_LAUNCH;
 
     const void *cur = x;
     for (int l = 0; l < L; ++l) {
