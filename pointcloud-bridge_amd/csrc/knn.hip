@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void knn_norms_kernel(const float *__rest
 // DP = D rounded up to a power of two >= 4; channels D..DP-1 are zero padding, which changes no
 // rounding step of the chain (fma(0, 0, acc) == acc) nor of the norms (s + 0*0 == s).
 template <int DP, int K>
-__global__ __launch_bounds__(kThreads) void knn_mfma_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(kThreads, 2) void knn_mfma_kernel(const float *__restrict__ x,
                                                              const float *__restrict__ norms, int N, int D,
                                                              int k, int64_t *__restrict__ out)
 {
@@ -148,12 +148,20 @@ __global__ __launch_bounds__(kThreads) void knn_mfma_kernel(const float *__restr
     float pre[NPT];
     float pre_n = 0.0f;
     auto fetch = [&](int base) {
+        if (D == DP && base + kTC <= N) {
+            // whole stage inside the cloud, rows DP wide: the stage is one contiguous block and a
+            // thread's elements sit at fixed strides from one (wave-uniform + lane) address
+            const float *__restrict__ sp = xb + (size_t)base * DP + t;
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int e = t + i * kThreads;
-            const int m = e / DP, c = e % DP;
-            const int row = base + m;
-            pre[i] = (row < N && c < D) ? xb[(size_t)row * D + c] : 0.0f;
+            for (int i = 0; i < NPT; ++i) pre[i] = sp[i * kThreads];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const int e = t + i * kThreads;
+                const int m = e / DP, c = e % DP;
+                const int row = base + m;
+                pre[i] = (row < N && c < D) ? xb[(size_t)row * D + c] : 0.0f;
+            }
         }
         if (t < kTC) pre_n = base + t < N ? norms[(size_t)b * N + base + t] : 0.0f;
     };
