@@ -349,6 +349,12 @@ int pcb_interpolate_bwd_csr_bf16(const void *grad_rows, int ld, int col0, const 
                                  const int *entries, int B, int N, int S, int C, int k, void *grad_feat,
                                  void *stream);
 
+/* Channel-attention gate of EnhancedFeaturePropagation (models/pointnet2_utils.py:279-280):
+ * out = x * sigmoid(a) on n bf16 elements (n % 8 == 0), one pass; backward dx = g*sigmoid(a),
+ * da = g*x*s*(1-s), one pass. */
+int pcb_gate_bf16(const void *x, const void *a, void *out, long n, void *stream);
+int pcb_gate_bwd_bf16(const void *g, const void *x, const void *a, void *dx, void *da, long n, void *stream);
+
 /*
  * A whole stack of L <= PCB_STACK_MAX_LAYERS shared-MLP layers  x -> act(BN(x W^T + b))  [-> max over
  * each `pool` consecutive rows]  enqueued from ONE call -- the loop the reference writes as

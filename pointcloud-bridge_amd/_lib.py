@@ -54,6 +54,8 @@ SIGNATURES = {
     "pcb_gather_add_partials": [_l, _i],
     "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p],
     "pcb_scatter_dy_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "pcb_gate_bf16": [_p, _p, _p, _l, _p],
+    "pcb_gate_bwd_bf16": [_p, _p, _p, _p, _p, _l, _p],
     "pcb_timer_start": [],
     "pcb_timer_enable": [_i],
     "pcb_timer_stop": [_p, _p, _p],

@@ -409,6 +409,43 @@ __global__ __launch_bounds__(kThreads) void group_rows_bf16_bwd_kernel(
     }
 }
 
+// Channel-attention gate of EnhancedFeaturePropagation (models/pointnet2_utils.py:279-280):
+// out = x * sigmoid(a), elementwise on bf16 rows, as ONE pass (the reference and autograd run
+// sigmoid and the product separately, and three passes in backward).
+__global__ __launch_bounds__(kThreads) void gate_kernel(const uint4 *__restrict__ x, const uint4 *__restrict__ a,
+                                                         uint4 *__restrict__ out, long nvec)
+{
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < nvec; e += (long)gridDim.x * kThreads) {
+        float fx[8], fa[8];
+        unpack8(x[e], fx);
+        unpack8(a[e], fa);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fx[i] = fx[i] / (1.0f + __expf(-fa[i]));
+        out[e] = pack8(fx);
+    }
+}
+
+// dx = g * sigmoid(a),  da = g * x * s * (1 - s)
+__global__ __launch_bounds__(kThreads) void gate_bwd_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ x,
+                                                             const uint4 *__restrict__ a, uint4 *__restrict__ dx,
+                                                             uint4 *__restrict__ da, long nvec)
+{
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < nvec; e += (long)gridDim.x * kThreads) {
+        float fg[8], fx[8], fa[8], d1[8], d2[8];
+        unpack8(g[e], fg);
+        unpack8(x[e], fx);
+        unpack8(a[e], fa);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sgm = 1.0f / (1.0f + __expf(-fa[i]));
+            d1[i] = fg[i] * sgm;
+            d2[i] = fg[i] * fx[i] * sgm * (1.0f - sgm);
+        }
+        dx[e] = pack8(d1);
+        da[e] = pack8(d2);
+    }
+}
+
 inline int grid_for(long work, int per_block = kThreads, int cap = 4096)
 {
     long blocks = (work + per_block - 1) / per_block;
@@ -555,5 +592,23 @@ extern "C" int pcb_bn_act_max_bwd_reduce_bf16(const float *dout, const unsigned 
     hipLaunchKernelGGL(bn_max_bwd_reduce_kernel, dim3(grid_for(groups, RT * 4, 2048)), dim3(kThreads), 0,
                        (hipStream_t)stream, dout, argmax, (const uint4 *)y, scale, shift, mean, invstd, groups,
                        C, ns, slope_of(act), sums);
+    return pcb_check_launch();
+}
+
+extern "C" int pcb_gate_bf16(const void *x, const void *a, void *out, long n, void *stream)
+{
+    if (!x || !a || !out || n <= 0 || (n & 7)) return PCB_ERR_INVALID_ARG;
+    const long nvec = n >> 3;
+    hipLaunchKernelGGL(gate_kernel, dim3(grid_for(nvec, kThreads, 8192)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4 *)x, (const uint4 *)a, (uint4 *)out, nvec);
+    return pcb_check_launch();
+}
+
+extern "C" int pcb_gate_bwd_bf16(const void *g, const void *x, const void *a, void *dx, void *da, long n, void *stream)
+{
+    if (!g || !x || !a || !dx || !da || n <= 0 || (n & 7)) return PCB_ERR_INVALID_ARG;
+    const long nvec = n >> 3;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(nvec, kThreads, 8192)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4 *)g, (const uint4 *)x, (const uint4 *)a, (uint4 *)dx, (uint4 *)da, nvec);
     return pcb_check_launch();
 }

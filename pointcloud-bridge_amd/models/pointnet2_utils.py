@@ -376,7 +376,7 @@ class EnhancedFeaturePropagation(nn.Module):
         x, perm = _propagate_rows(xyz1, xyz2, points1, points2, 4)
         att = self.attention                                        # :279-280
         a = rowmlp.conv_bn_act(att[0], att[1], x, rowmlp.ACT_RELU, perm=perm)
-        x = x * torch.sigmoid(rowmlp.conv_rows(att[3], a, out_gap=-perm))
+        x = rowmlp.gate_rows(x, rowmlp.conv_rows(att[3], a, out_gap=-perm))
         edge = _seq_rows(self.boundary_aware, xyz1.reshape(B * N, 3))  # :283
         identity = x
         x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x, perm=perm)

@@ -769,6 +769,36 @@ class _BNActRows(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
+class _Gate(torch.autograd.Function):
+    """x * sigmoid(a) on bf16 rows in one pass each way (pcb_gate_bf16 / pcb_gate_bwd_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _launch("pcb_gate_bf16", x.numel(), x.data_ptr(), a.data_ptr(), out.data_ptr(), x.numel())
+        ctx.save_for_backward(x, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a = ctx.saved_tensors
+        g = g.to(torch.bfloat16).contiguous()
+        dx, da = torch.empty_like(x), torch.empty_like(a)
+        with torch.cuda.device(x.device):
+            _launch("pcb_gate_bwd_bf16", 3 * x.numel(), g.data_ptr(), x.data_ptr(), a.data_ptr(), dx.data_ptr(),
+                    da.data_ptr(), x.numel())
+        return dx, da
+
+
+def gate_rows(x, a):
+    """x * sigmoid(a) (the channel-attention gate, reference pointnet2_utils.py:279-280)."""
+    if (is_bf16() and x.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and x.shape == a.shape
+            and x.is_contiguous() and a.is_contiguous() and x.numel() % 8 == 0):
+        return _Gate.apply(x, a)
+    return x * torch.sigmoid(a)
+
+
 def bn_act_rows(bn, x, act=ACT_NONE):
     """BatchNorm (+ activation) on rows without a preceding conv (DGCNN.local_bn)."""
     if not is_bf16():

@@ -535,3 +535,26 @@ def test_gather_add_and_scatter_dy_entry_points(rm, pooled, with_v, with_wx):
     assert torch.allclose(dv, dv_ref, rtol=1e-4, atol=1e-4)
     if with_wx:
         assert torch.allclose(dwx[0], dy.t() @ diff, rtol=1e-4, atol=1e-3)
+
+
+def test_gate_rows_matches_torch(rm):
+    """pcb_gate_bf16 / pcb_gate_bwd_bf16 == x * sigmoid(a) and its autograd gradients (bf16 rounding)."""
+    dev = torch.device("cuda")
+    torch.manual_seed(2)
+    x = torch.randn(777, 264, device=dev).to(torch.bfloat16)
+    a = (torch.randn(777, 264, device=dev) * 3).to(torch.bfloat16)
+    g = torch.randn(777, 264, device=dev).to(torch.bfloat16)
+    rm.set_precision("bf16")
+    try:
+        x1, a1 = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+        out = rm.gate_rows(x1, a1)
+        out.backward(g)
+    finally:
+        rm.set_precision("fp32")
+    x2, a2 = x.float().requires_grad_(True), a.float().requires_grad_(True)
+    ref = x2 * torch.sigmoid(a2)
+    ref.backward(g.float())
+    assert out.dtype == torch.bfloat16
+    assert torch.allclose(out.float(), ref, rtol=2 ** -7, atol=1e-3)
+    assert torch.allclose(x1.grad.float(), x2.grad, rtol=2 ** -7, atol=1e-3)
+    assert torch.allclose(a1.grad.float(), a2.grad, rtol=2 ** -7, atol=1e-3)
