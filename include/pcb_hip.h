@@ -190,11 +190,13 @@ int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream
  * count/(count-1); 0 means rows.  (It exceeds rows when every row is a sample repeated count/rows
  * times -- nearest-neighbour upsampling before the layer, models/model.py:164 -- whose mean and
  * biased variance equal those of the distinct rows.)
+ * num_batches_tracked (optional, int64 scalar on the device): incremented by one -- the counter
+ * nn.BatchNorm.forward bumps in training mode.
  */
 int pcb_bn_finalize(const float *sums, int nparts, long rows, long count, int C, const float *gamma, const float *beta,
                     const float *bias, float *running_mean, float *running_var, float momentum,
                     float eps, int training, float *scale, float *shift, float *mean, float *invstd,
-                    void *stream);
+                    long long *num_batches_tracked, void *stream);
 
 /* z = act(y*scale + shift), y/z [rows,C] bf16. */
 int pcb_bn_act_bf16(const void *y, const float *scale, const float *shift, long rows, int C, int act,
@@ -372,6 +374,7 @@ int pcb_gate_bwd_bf16(const void *g, const void *x, const void *a, void *dx, voi
  *   [8] 1: batch statistics (training), 0: running statistics
  *   [9] y bf16 [R,C]: the layer's pre-BatchNorm GEMM output (written by forward, read by backward)
  *   [10] dW fp32 [C,k]  [11] dgamma [C]  [12] dbeta [C]  [13] dbias [C]   (backward outputs, any may be 0)
+ *   [14] num_batches_tracked (int64 scalar, forward: += 1) or 0
  * fdesc: L x 2 doubles: momentum, eps.  stat_repeat >= 1: every row of x stands for that many
  * identical samples (see pcb_bn_finalize `count`); 1 otherwise.
  * x bf16 [R,Kp] rows in the column layout `perm` (see pcb_prep_weights_bf16); act 0/1/2;

@@ -101,9 +101,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float *__restrict__ sums, int nparts, long rows, long count, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ bias, float *__restrict__ running_mean,
     float *__restrict__ running_var, float momentum, float eps, int training, float *__restrict__ scale,
-    float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out)
+    float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out,
+    long long *__restrict__ num_batches_tracked)
 {
     __shared__ float red[2][32][32];
+    // nn.BatchNorm's step counter (num_batches_tracked += 1 in a train-mode forward), bumped here
+    // instead of by one more tiny launch per module
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s1 = 0.0f, s2 = 0.0f;
@@ -469,13 +473,14 @@ extern "C" int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, v
 extern "C" int pcb_bn_finalize(const float *sums, int nparts, long rows, long count, int C, const float *gamma,
                                const float *beta, const float *bias, float *running_mean,
                                float *running_var, float momentum, float eps, int training,
-                               float *scale, float *shift, float *mean, float *invstd, void *stream)
+                               float *scale, float *shift, float *mean, float *invstd,
+                               long long *num_batches_tracked, void *stream)
 {
     if (!scale || !shift || !mean || !invstd || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
     if (training ? (!sums || nparts < 1) : (!running_mean || !running_var)) return PCB_ERR_INVALID_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, nparts,
                        rows, count > 0 ? count : rows, C, gamma, beta, bias, running_mean, running_var, momentum, eps, training,
-                       scale, shift, mean, invstd);
+                       scale, shift, mean, invstd, num_batches_tracked);
     return pcb_check_launch();
 }
 

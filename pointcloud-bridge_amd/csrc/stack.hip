@@ -135,7 +135,7 @@ extern "C" int pcb_timer_stop(long *launches, double *milliseconds, double *byte
 // ---- stack descriptors ------------------------------------------------------------------------
 namespace {
 constexpr int kSlots = 16;  // int64 slots per layer, see include/pcb_hip.h
-enum { S_W = 0, S_BIAS, S_GAMMA, S_BETA, S_RMEAN, S_RVAR, S_C, S_K, S_TRAIN, S_Y, S_DW, S_DGAMMA, S_DBETA, S_DBIAS };
+enum { S_W = 0, S_BIAS, S_GAMMA, S_BETA, S_RMEAN, S_RVAR, S_C, S_K, S_TRAIN, S_Y, S_DW, S_DGAMMA, S_DBETA, S_DBIAS, S_NBT };
 
 struct Layer {
     const float *w, *bias, *gamma, *beta;
@@ -143,6 +143,7 @@ struct Layer {
     int C, k, training;
     void *y;
     float *dW, *dgamma, *dbeta, *dbias;
+    long long *nbt;  // num_batches_tracked or NULL
     int kp;          // padded input width (= previous layer's C, or the stack's Kp)
     long wp_off;     // element offsets into the bf16 weight buffer
     long wt_off;     // -1: no transposed copy
@@ -174,6 +175,7 @@ int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, Lay
         a.dgamma = ptr<float>(d[S_DGAMMA]);
         a.dbeta = ptr<float>(d[S_DBETA]);
         a.dbias = ptr<float>(d[S_DBIAS]);
+        a.nbt = ptr<long long>(d[S_NBT]);
         if (gathered && l == 0) {
             // layer 0 = gather_add of per-point products: no weights of its own in this call
             if (!a.y || a.C <= 0 || (a.C & 7)) return PCB_ERR_INVALID_ARG;
@@ -345,7 +347,7 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
         }
         PCB_TRY(pcb_bn_finalize(stats ? parts : nullptr, nparts, R, R * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma, a.beta, a.bias, a.rmean, a.rvar,
                                 (float)fdesc[2 * l], (float)fdesc[2 * l + 1], a.training, row(stz, a, 2),
-                                row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), stream));
+                                row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), a.nbt, stream));
         cur = a.y;
     }
     const Layer &last = ly[L - 1];

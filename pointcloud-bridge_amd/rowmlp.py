@@ -139,7 +139,7 @@ class _LinearBNAct(torch.autograd.Function):
                     0 if running_mean is None else running_mean.data_ptr(),
                     0 if running_var is None else running_var.data_ptr(),
                     float(momentum), float(eps), int(training), scale.data_ptr(), shift.data_ptr(),
-                    mean.data_ptr(), invstd.data_ptr())
+                    mean.data_ptr(), invstd.data_ptr(), 0)
             if pool:
                 G = R // pool
                 out = torch.empty(G, C, dtype=torch.bfloat16, device=dev)
@@ -222,6 +222,15 @@ def _unpad_weight_grad(dwp, k, perm):
     return dwp[:, :k]
 
 
+def _counter(bn):
+    """The module's num_batches_tracked if this forward has to increment it on the device (the
+    momentum=None case increments it on the host in _bn_bookkeeping, which also reads it)."""
+    if (bn.training and bn.track_running_stats and bn.num_batches_tracked is not None
+            and bn.momentum is not None and bn.num_batches_tracked.is_cuda):
+        return bn.num_batches_tracked
+    return None
+
+
 def _bn_bookkeeping(bn):
     """momentum to use for this call + the num_batches_tracked increment of nn.BatchNorm.forward."""
     eaf = 0.0 if bn.momentum is None else bn.momentum
@@ -247,9 +256,10 @@ class _FusedStack(torch.autograd.Function):
     max-pooled over `pool` consecutive rows.
 
     Flat argument list: x, act, pool, perm, stat_repeat, L, then per layer
-    (weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps)."""
+    (weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
+    num_batches_tracked or None -- incremented by the finalize kernel)."""
 
-    NPER = 9
+    NPER = 10
 
     @staticmethod
     def forward(ctx, x, act, pool, perm, stat_repeat, L, *flat):
@@ -381,9 +391,10 @@ class _GatheredStack(torch.autograd.Function):
     returns du, dv, dwx; autograd takes du, dv on through the caller's point_linear calls.
 
     Flat argument list: u, v, wx, xyz, ctr, idx, ns, act, pool, L, then per layer (weight, bias,
-    gamma, beta, running_mean, running_var, training, momentum, eps); layer 0's weight is None."""
+    gamma, beta, running_mean, running_var, training, momentum, eps, num_batches_tracked or None);
+    layer 0's weight is None."""
 
-    NPER = 9
+    NPER = 10
     NHEAD = 10
 
     @staticmethod
@@ -476,11 +487,6 @@ def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0, wx=None, xyz=None,
     B, S, ns = idx.shape
     if pool not in (0, ns):
         raise ValueError("a gathered stack pools over its own neighbour axis")
-    counted = [bn.num_batches_tracked for bn in bns
-               if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None
-               and bn.momentum is not None]
-    if counted:
-        torch._foreach_add_(counted, 1)
     flat = []
     for i, (conv, bn) in enumerate(zip(convs, bns)):
         momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
@@ -489,7 +495,7 @@ def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0, wx=None, xyz=None,
         flat += [conv.weight if i else None, conv.bias, bn.weight, bn.bias,
                  bn.running_mean if (track or not training) else None,
                  bn.running_var if (track or not training) else None,
-                 training, momentum, bn.eps]
+                 training, momentum, bn.eps, _counter(bn)]
     return _GatheredStack.apply(u.contiguous(), None if v is None else v.contiguous(),
                                 None if wx is None else wx.contiguous(),
                                 None if wx is None else xyz.contiguous(), None if wx is None else ctr.contiguous(),
@@ -529,7 +535,8 @@ def _stack_desc(layers, widths, ybuf, R, outs=None):
                  0 if rv is None else rv.data_ptr(), C, 0 if w is None else w.numel() // C, int(bool(training)),
                  ybase + 2 * yoff,
                  0 if o[0] is None else o[0].data_ptr(), 0 if o[1] is None else o[1].data_ptr(),
-                 0 if o[2] is None else o[2].data_ptr(), 0 if o[3] is None else o[3].data_ptr(), 0, 0]
+                 0 if o[2] is None else o[2].data_ptr(), 0 if o[3] is None else o[3].data_ptr(),
+                 t[9].data_ptr() if (len(t) > 9 and t[9] is not None) else 0, 0]
         yoff += R * C
     return (ctypes.c_longlong * len(vals))(*vals)
 
@@ -542,13 +549,8 @@ def _fused_stack(convs, bns, x, act, pool, perm, stat_repeat=1):
     kp = x.shape[1] if perm != 0 else pad8(convs[0].in_channels)
     xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
     flat = []
-    # num_batches_tracked += 1 of all the stack's BatchNorms in one multi-tensor launch
-    # (nn.BatchNorm.forward does it per module); the count itself is only read when momentum=None
-    counted = [bn.num_batches_tracked for bn in bns
-               if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None
-               and bn.momentum is not None]
-    if counted:
-        torch._foreach_add_(counted, 1)
+    # num_batches_tracked += 1 (nn.BatchNorm.forward does it per module) rides along in the layer's
+    # finalize kernel; the count itself is only read on the host when momentum=None
     for conv, bn in zip(convs, bns):
         momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
         training = bn.training or (bn.running_mean is None and bn.running_var is None)
@@ -556,7 +558,7 @@ def _fused_stack(convs, bns, x, act, pool, perm, stat_repeat=1):
         flat += [conv.weight, conv.bias, bn.weight, bn.bias,
                  bn.running_mean if (track or not training) else None,
                  bn.running_var if (track or not training) else None,
-                 training, momentum, bn.eps]
+                 training, momentum, bn.eps, _counter(bn)]
     return _FusedStack.apply(xr, act, pool, perm, stat_repeat, len(convs), *flat)
 
 
@@ -746,7 +748,7 @@ class _BNActRows(torch.autograd.Function):
                     0 if running_mean is None else running_mean.data_ptr(),
                     0 if running_var is None else running_var.data_ptr(),
                     float(momentum), float(eps), int(training), stats[2].data_ptr(), stats[3].data_ptr(),
-                    stats[4].data_ptr(), stats[5].data_ptr())
+                    stats[4].data_ptr(), stats[5].data_ptr(), 0)
             _launch("pcb_bn_act_bf16", R * C, y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), R, C, act,
                     out.data_ptr())
         ctx.save_for_backward(y, stats)

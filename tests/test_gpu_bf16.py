@@ -352,6 +352,7 @@ def test_stack_call_equals_layer_by_layer_calls(rm):
                 h = rm.conv_bn_act(c, b, h, pool=pool if i == len(convs) - 1 else 0)
             out = h
         out.float().square().sum().backward()
+        assert all(int(b.num_batches_tracked) == 1 for b in bns)  # bumped by the finalize kernel, once
         return (out.detach().float(), x.grad.float(), [c.weight.grad.clone() for c in convs],
                 [b.weight.grad.clone() for b in bns], [b.running_var.clone() for b in bns])
 
