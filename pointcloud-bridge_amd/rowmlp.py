@@ -100,22 +100,6 @@ def _mm_f32out(a, b):
         return torch.mm(a, b).float()
 
 
-def padded_weight(conv, kp, perm_feat_first=0):
-    """[Cout, kp] bf16 copy of a 1x1 conv weight, zero padded.  perm_feat_first = C > 0 moves the
-    first 3 input columns (centred coordinates, reference order :56/:347) behind the C feature
-    columns, the order pcb_group_rows_bf16 writes."""
-    w = _weight2d(conv)
-    cout, k = w.shape
-    wp = torch.zeros(cout, kp, dtype=torch.bfloat16, device=w.device)
-    if perm_feat_first > 0:
-        c = perm_feat_first
-        wp[:, :c] = w[:, 3:3 + c]
-        wp[:, c:c + 3] = w[:, :3]
-    else:
-        wp[:, :k] = w
-    return wp
-
-
 class _LinearBNAct(torch.autograd.Function):
     """x [R,Kp] bf16 -> act(BN(x @ W^T)) as rows [R,C] bf16, or pooled over `pool` consecutive rows
     ([R/pool, C] bf16).  Saves x, the bf16 GEMM output y and the per-channel statistics only."""
