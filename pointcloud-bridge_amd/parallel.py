@@ -52,13 +52,16 @@ class FlatGradAllReduce:
     reduce() packs them into ONE flat fp32 buffer with one concatenation, all-reduces it once and
     hands each parameter a view of the averaged buffer.  With a single rank both are no-ops."""
 
-    def __init__(self, params, group=None, keep_grad_tensors=False):
+    def __init__(self, params, group=None, keep_grad_tensors=False, assign_views=True):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         # keep_grad_tensors: the averaged values are copied back into the existing .grad tensors
         # instead of re-pointing .grad at the flat buffer (needed when a captured hipGraph writes
         # the gradients into fixed tensors on every replay)
         self.keep = keep_grad_tensors
+        # assign_views=False: the caller consumes .flat itself (FlatAdam.step(bucket.flat)); the
+        # per-parameter .grad tensors are left as they are (NOT averaged)
+        self.assign_views = assign_views
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.flat = None
         for p in self.params:
@@ -77,6 +80,10 @@ class FlatGradAllReduce:
         self.flat = torch.cat([p.grad.reshape(-1) for p in live])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(self.world)
+        if not self.assign_views:
+            if len(live) != len(self.params):
+                raise RuntimeError("FlatGradAllReduce: a parameter has no gradient (flat layout would shift)")
+            return
         off = 0
         views = []
         for p in live:
@@ -88,6 +95,51 @@ class FlatGradAllReduce:
         else:
             for p, v in zip(live, views):
                 p.grad = v
+
+
+class FlatAdam:
+    """torch.optim.Adam (the reference's optimiser, train_MulSca_PN2.py:125: Adam with L2 weight
+    decay) over ONE flat fp32 buffer: the parameters become views of it, the gradients arrive as one
+    flat tensor (FlatGradAllReduce.flat, or one concatenation here), and the update is a single
+    fused elementwise kernel instead of a multi-tensor launch chain over ~150 tensors.  The
+    arithmetic per element is torch's fused Adam (torch._fused_adam_), so results match
+    torch.optim.Adam(fused=True) bit for bit."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
+            raise TypeError("FlatAdam expects fp32 parameters on one device")
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.flat = torch.cat([p.detach().reshape(-1) for p in self.params])
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.data = self.flat[off:off + n].view_as(p)  # same values, storage inside the flat buffer
+            off += n
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def step(self, flat_grad=None):
+        """flat_grad: the gradients already packed in parameter order (FlatGradAllReduce.flat), else
+        they are concatenated here.  Every parameter must have a gradient."""
+        if flat_grad is None:
+            if any(p.grad is None for p in self.params):
+                raise RuntimeError("FlatAdam.step: a parameter has no gradient")
+            flat_grad = torch.cat([p.grad.reshape(-1) for p in self.params])
+        if flat_grad.numel() != self.flat.numel():
+            raise ValueError("flat gradient does not match the parameters")
+        self.step_t += 1
+        torch._fused_adam_([self.flat], [flat_grad], [self.exp_avg], [self.exp_avg_sq], [], [self.step_t],
+                           lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], weight_decay=self.weight_decay,
+                           eps=self.eps, amsgrad=False, maximize=False)
 
 
 def broadcast_parameters(module, src=0, group=None):

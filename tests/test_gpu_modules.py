@@ -4,6 +4,8 @@ Same seeded parameters (the modules create theirs in the reference's order), sam
 generator seed in front of each forward (farthest_point_sample draws its start index there).
 Bar from BASELINE.json: segmentation logits within 1e-4 relative (max |diff| / max |reference|).
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -203,3 +205,22 @@ def test_sampling_prefetch_gives_identical_results(mpu):
     assert torch.equal(after_inline, after_pre)          # same number of CPU draws consumed
     assert rel_err(pre, g["logits_eval"]) < REL
     assert len(mpu._prefetched) == 0                     # every level was picked up
+
+
+def test_flat_adam_equals_torch_fused_adam():
+    """parallel.FlatAdam (one flat buffer, one fused launch) == torch.optim.Adam(fused=True), bit for bit."""
+    from pointcloud_bridge_amd.parallel import FlatAdam
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(13, 32), torch.nn.BatchNorm1d(32), torch.nn.Linear(32, 5)).to(dev)
+    mine = copy.deepcopy(ref)
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4, fused=True)
+    o_mine = FlatAdam(mine.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4)
+    x = torch.randn(64, 13, device=dev)
+    for _ in range(5):
+        for m, o in ((ref, o_ref), (mine, o_mine)):
+            o.zero_grad(set_to_none=True)
+            m(x).square().mean().backward()
+            o.step()
+    for a, b in zip(ref.parameters(), mine.parameters()):
+        assert torch.equal(a, b)
