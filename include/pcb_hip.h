@@ -265,6 +265,12 @@ int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale
  * per-point products of csrc/gatherlin.hip (replaces torch.matmul on R = B*N rows). */
 int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int N, int K, float *out, void *stream);
 
+/* Tell the library that another kernel occupies about `busy_cus` compute units beside the launches
+ * that follow (e.g. the next batch's FPS on a side stream during the backward pass): the persistent
+ * input-gradient GEMMs then size their grids for the remaining CUs.  0 = the GPU is ours (default).
+ * Query pcb_gemm_nt_partials AFTER setting the hint: the slab count follows the grid. */
+int pcb_set_concurrency_hint(int busy_cus);
+
 /* Number of per-workgroup statistics slabs pcb_gemm_nt_bf16 writes for these sizes. */
 int pcb_gemm_nt_partials(int pro, long R, int N);
 

@@ -773,6 +773,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(float *__restrict
     q[c] = fmaf(sb, mean[c], -scale[c] * a);
 }
 
+// CUs to leave free while another kernel runs beside the backward pass (pcb_set_concurrency_hint).
+// Measured with the FPS kernel of the next batch on a side stream (16 workgroups): a 512-workgroup
+// persistent gemm_nt slows from 145 to 220 us, one of 448 runs in 163 us either way -- the persistent
+// grid assumes it owns every CU, and the workgroups that find their CU taken serialise behind others.
+long g_shared_cus = 0;
+
 // Workgroups along x of a gemm_nt launch (= slabs of its partials buffer): persistent over row
 // tiles, as many as are resident at once -- 3 per CU for the forward prologues, 2 for the
 // register-heavier backward ones (see the launch bounds of gemm_nt_kernel).
@@ -780,8 +786,9 @@ long nt_grid_x(int pro, long R, int N)
 {
     const long tiles = (R + NT_BM - 1) / NT_BM;
     const long ny = (N + NT_BN - 1) / NT_BN;
-    static const long fwd_chip = getenv("PCB_NT_FWD_GRID") ? atol(getenv("PCB_NT_FWD_GRID")) : 768;  // tuning knob
-    const long chip = pro <= PRO_BNACT ? fwd_chip : 512;
+    static const long fwd_chip = getenv("PCB_NT_FWD_GRID") ? atol(getenv("PCB_NT_FWD_GRID")) : 768;  // tuning knobs
+    static const long bwd_chip = getenv("PCB_NT_BWD_GRID") ? atol(getenv("PCB_NT_BWD_GRID")) : 512;
+    const long chip = pro <= PRO_BNACT ? fwd_chip : bwd_chip - 2 * g_shared_cus;
     const long resident = chip / ny > 0 ? chip / ny : 1;
     return tiles < resident ? tiles : resident;
 }
@@ -891,7 +898,9 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
     if (pro >= PRO_DY && !sums && N > NT_BN && K <= 256) {
         // wide input gradient: transformed A tile resident in LDS, column tiles walked inside
         const long tiles = (R + AR_BM - 1) / AR_BM;
-        const dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
+        static const long ares_base = getenv("PCB_NT_BWD_GRID") ? atol(getenv("PCB_NT_BWD_GRID")) : 512;
+        const long ares_chip = ares_base - 2 * g_shared_cus;
+        const dim3 grid((unsigned)(tiles < ares_chip ? tiles : ares_chip));
         if (pro == PRO_DY) {
             if (K <= 128)
                 hipLaunchKernelGGL((gemm_nt_ares_kernel<PRO_DY, 16>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out);
@@ -958,6 +967,12 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
     else
         launch_tn<PRO_DY_POOL>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
     return pcb_check_launch();
+}
+
+extern "C" int pcb_set_concurrency_hint(int busy_cus)
+{
+    g_shared_cus = busy_cus < 0 ? 0 : (busy_cus > 64 ? 64 : busy_cus);
+    return PCB_OK;
 }
 
 extern "C" int pcb_gemm_nt_partials(int pro, long R, int N)

@@ -82,6 +82,8 @@ def prefetch_sampling(xyz, npoints):
             ev.record(_side_stream)
             _prefetched[_key(cur, npoint)] = (idx, new_xyz, ev)
             cur = new_xyz
+    # one FPS workgroup per scene; the GEMMs beside it leave twice that many CUs alone (measured)
+    ops.set_background_work(ev, 2 * xyz.shape[0])
 
 
 class StaticSampling:

@@ -40,6 +40,34 @@ def kernel_timer_stop():
     return n.value, ms.value, by.value
 
 
+# A kernel running beside the main stream (the FPS pyramid of the next batch, models/pointnet2_utils.
+# prefetch_sampling) takes CUs away from the persistent GEMMs of the backward pass; while its event
+# is pending the library is told to size those grids for the rest of the chip.
+_background = None  # (event, busy_cus)
+_hint_now = 0
+
+
+def set_background_work(event, busy_cus):
+    global _background
+    _background = (event, int(busy_cus))
+
+
+def apply_concurrency_hint():
+    """Call before a batch of backward launches: forwards the current state to the library."""
+    global _background, _hint_now
+    want = 0
+    if _background is not None:
+        if torch.cuda.is_current_stream_capturing():
+            want = _background[1]       # a captured step always runs beside its own FPS pyramid
+        elif _background[0].query():
+            _background = None          # finished: the GPU is ours again
+        else:
+            want = _background[1]
+    if want != _hint_now:
+        _lib.load().pcb_set_concurrency_hint(want)
+        _hint_now = want
+
+
 def _launch(name, units, *args):
     """Call entry point `name` of libpcb_hip.so on the current stream; raise on a bad status.
     (`units` documents the call's work at the call site; timing lives in the library.)"""

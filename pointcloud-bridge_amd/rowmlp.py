@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import _launch
+from .ops import _launch, apply_concurrency_hint
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 _PRECISION = "fp32"
@@ -309,6 +309,7 @@ class _FusedStack(torch.autograd.Function):
         dzbuf = torch.empty(2 * R * maxw, dtype=torch.bfloat16, device=dev) if L > 1 else None
         parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
+        apply_concurrency_hint()
         with torch.cuda.device(dev):
             _launch("pcb_mlp_stack_backward", 0, L, desc, x.data_ptr(), g.data_ptr(),
                     0 if arg is None else arg.data_ptr(), R, Kp, perm, act, pool, int(need_dx), 0, wbuf.data_ptr(),
@@ -455,6 +456,7 @@ class _GatheredStack(torch.autograd.Function):
         dzbuf = torch.empty(2 * R * max([8] + widths[:-1]), dtype=torch.bfloat16, device=dev) if L > 1 else None
         parts = torch.empty(max(_MAX_PARTS, 1024) * 2 * max(widths), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
+        apply_concurrency_hint()
         with torch.cuda.device(dev):
             _launch("pcb_mlp_stack_backward", 0, L, desc, 0, g.data_ptr(), 0 if arg is None else arg.data_ptr(), R, 0,
                     0, act, pool, 0, gather, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), ws.data_ptr(),
