@@ -810,10 +810,10 @@ void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, 
 
 // Row splits of the weight-gradient GEMM: enough workgroups to fill the chip (~1024), at least 8
 // stages of work each.  Returns the split count; *rows_per_split is a multiple of TN_RS.
-long tn_splits(long R, int M, int N, long *rows_per_split)
+long tn_splits(long R, int M, int N, long *rows_per_split, long target = 512)
 {
     const long tiles = (long)((M + TN_BM - 1) / TN_BM) * ((N + TN_BN - 1) / TN_BN);
-    long splits = (512 + tiles - 1) / tiles;
+    long splits = (target + tiles - 1) / tiles;
     const long max_splits = (R + 8 * TN_RS - 1) / (8 * TN_RS);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -828,7 +828,8 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
                int out_cols, int out_perm, hipStream_t st)
 {
     long rps;
-    const long splits = tn_splits(R, M, N, &rps);
+    // fewer splits while another kernel holds CUs (never more than pcb_gemm_tn_workspace assumed)
+    const long splits = tn_splits(R, M, N, &rps, 512 - 2 * g_shared_cus);
     const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
     const dim3 grid((unsigned)(tm * tn * splits));
     if (bpro == PRO_PLAIN)
