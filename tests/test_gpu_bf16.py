@@ -472,8 +472,9 @@ def test_gathered_first_layer_matches_grouped_rows(rm, kind):
         assert eg <= max(1.6 * er, 3e-2), (n, eg, er)
 
 
-@pytest.mark.parametrize("pooled,with_v,with_wx", [(0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1)])
-def test_gather_add_and_scatter_dy_entry_points(rm, pooled, with_v, with_wx):
+@pytest.mark.parametrize("pooled,with_v,with_wx,C", [(0, 1, 0, 64), (1, 1, 0, 64), (0, 0, 1, 64), (1, 0, 1, 64),
+                                                      (0, 1, 1, 192), (1, 1, 0, 520), (0, 0, 1, 8)])
+def test_gather_add_and_scatter_dy_entry_points(rm, pooled, with_v, with_wx, C):
     """pcb_gather_add_bf16 / pcb_scatter_dy_bf16 against a direct PyTorch evaluation of their
     definitions (include/pcb_hip.h): rows, BatchNorm statistics slabs, du / dv / dWx."""
     import ctypes
@@ -481,7 +482,7 @@ def test_gather_add_and_scatter_dy_entry_points(rm, pooled, with_v, with_wx):
     from pointcloud_bridge_amd.ops import _launch
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(21)
-    B, N, S, ns, C = 2, 96, 40, 8, 64
+    B, N, S, ns = 2, 96, 40, 8
     R = B * S * ns
     u = torch.randn(B * N, C, generator=g).to(dev)
     v = torch.randn(B * S, C, generator=g).to(dev) if with_v else None
