@@ -60,7 +60,8 @@ class DGCNN(nn.Module):
         B, N, D = x.shape
         xf = x.float()
         idx = ops.knn(xf, k)  # the graph is always built from fp32 distances
-        if x.requires_grad and D >= 32 and D % 8 == 0 and rowmlp.gathered_ok([block[0]], [block[1]]):
+        if ((x.requires_grad or not torch.is_grad_enabled()) and D >= 32 and D % 8 == 0
+                and rowmlp.gathered_ok([block[0]], [block[1]])):
             # W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i: per-point products, gathered by the graph
             # (rowmlp.gathered_mlp); the [B*N*k, 2D] edge tensor is never written
             w = block[0].weight.view(block[0].out_channels, 2 * D)

@@ -228,7 +228,8 @@ def _grouped_mlp(convs, bns, xyz, new_xyz, feat, idx):
     (3+C)-wide row gradient shrink to C0-wide gathers/scatters.  Otherwise rows are grouped first."""
     B, S, ns = idx.shape
     cf = 0 if feat is None else feat.shape[2]
-    if (feat is not None and feat.requires_grad and cf >= 32 and cf % 8 == 0
+    # (with gradients off -- inference -- the gathered form is simply the cheaper forward)
+    if (feat is not None and (feat.requires_grad or not torch.is_grad_enabled()) and cf >= 32 and cf % 8 == 0
             and rowmlp.gathered_ok(convs, bns)):
         N = xyz.shape[1]
         w0 = convs[0].weight.view(convs[0].out_channels, 3 + cf)
