@@ -53,23 +53,38 @@ __global__ __launch_bounds__(T) void fps_regs_kernel(const float *__restrict__ x
         const float cz = p[far * 3 + 2];
 
         float best = -2.0f;
-        int besti = kPad;
+        // two points per instruction: packed fp32 subtract / multiply / add round each component
+        // exactly like the scalar operations (and -ffp-contract=off keeps them unfused)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
+        for (int q = 0; q + 1 < P; q += 2) {
+            const f2 dx = f2{px[q], px[q + 1]} - cx2;
+            const f2 dy = f2{py[q], py[q + 1]} - cy2;
+            const f2 dz = f2{pz[q], pz[q + 1]} - cz2;
+            const f2 d = (dx * dx + dy * dy) + dz * dz;
+            // d >= 0 and never NaN here, so the hardware minimum IS the reference's `d < run ? d : run`
+            run[q] = __builtin_fminf(d.x, run[q]);
+            run[q + 1] = __builtin_fminf(d.y, run[q + 1]);
+            best = __builtin_fmaxf(best, __builtin_fmaxf(run[q], run[q + 1]));
+        }
+        if (P & 1) {
+            const int q = P - 1;
             const float dx = __fsub_rn(px[q], cx);
             const float dy = __fsub_rn(py[q], cy);
             const float dz = __fsub_rn(pz[q], cz);
             const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            run[q] = d < run[q] ? d : run[q];
-            // ascending q = ascending index inside the lane: strict ">" keeps the first maximum
-            if (run[q] > best) {
-                best = run[q];
-                besti = q * T + t;
-            }
+            run[q] = __builtin_fminf(d, run[q]);
+            best = __builtin_fmaxf(best, run[q]);
         }
-        // wave: maximum value, then the lowest index that attains it
+        // wave: maximum value first, THEN the lowest index that attains it -- the per-point
+        // (compare, select value, select index) of a running arg-max becomes one max per point plus
+        // one compare/select per point against the wave's maximum
         const float wmax = wave_max(best);
-        const int wcand = wave_min(best == wmax ? besti : kPad);
+        int besti = kPad;
+#pragma unroll
+        for (int q = P - 1; q >= 0; --q) besti = run[q] == wmax ? q * T + t : besti;  // lowest q wins
+        const int wcand = wave_min(besti);
         if (NW == 1) {
             far = wcand;
         } else {
