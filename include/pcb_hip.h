@@ -149,6 +149,21 @@ int pcb_interpolate_bwd(const float *grad_out, const float *w, const int64_t *id
 int pcb_knn(const float *x, int B, int N, int D, int k, float *norms, int64_t *out_idx, void *stream);
 
 /*
+ * Local-structure descriptor of the k-neighbourhood of every point.  Replaces the neighbour gather
+ * and get_structure_features of BridgeStructureEncoding, models/attention_modules.py:595-603 and
+ * :620-687 (rel = x_j - x_i; ascending eigenvalues e of rel^T rel/(k-1) by batched eigh; the
+ * [B*N,k,k] direction-similarity bmm; std() unbiased).
+ *   xyz [B,N,3] fp32, idx [B,N,k] int64 (e.g. from pcb_knn with D = 3; clamped to [0,N-1])
+ *   feat [B,N,13] fp32 = ((e0-e1)/(e0+1e-8), (e1-e2)/(e0+1e-8), e2/(e0+1e-8), max/mean/std of
+ *        |rel - mean(rel)|, mean_jl(n_j.n_l) with n = rel/(|rel|+1e-8), std(rel_z), range(rel_z),
+ *        mean(rel) (3), |std(rel)|) in the reference's order (:674-681)
+ *   rel  [B,N,k,3] fp32 or NULL: the offsets themselves (:600), for the encoder's first layer
+ * Requires 2 <= k <= 32 (k = 1 makes the reference's std() NaN).
+ */
+int pcb_structure_features(const float *xyz, const int64_t *idx, int B, int N, int k, float *feat,
+                           float *rel, void *stream);
+
+/*
  * EdgeConv edge features.  Replaces the gather/repeat/cat of DGCNN.get_graph_feature,
  * models/DGCNN.py:90-107: out[b,n,j,:] = cat(x[b,idx[b,n,j]] - x[b,n], x[b,n]).
  *   x [B,N,D], idx [B,N,k] int64, out [B,N,k,2D]   (channels-last; the reference's [B,2D,N,k]

@@ -146,3 +146,42 @@ def edge_features(x_bnd, idx):
     ctr = np.broadcast_to(x[:, :, None, :], nb.shape)
     f = np.concatenate([nb - ctr, ctr], axis=3)
     return np.ascontiguousarray(f.transpose(0, 3, 1, 2))
+
+
+def cdist_knn(xyz, k):
+    """attention_modules.py:584-586: Euclidean distance matrix, k smallest per row -> [B,N,k] int64.
+    numpy restatement of torch.cdist's matmul route (|a|^2 + |b|^2 - 2ab, clamped at 0, sqrt);
+    candidates tied at the k-th place may differ from ATen's topk -- compare as sets."""
+    x = _f32(xyz).astype(np.float64)
+    n2 = (x * x).sum(-1)
+    d2 = n2[:, :, None] + n2[:, None, :] - 2.0 * np.einsum("bnc,bmc->bnm", x, x)
+    d = np.sqrt(np.maximum(d2, 0.0)).astype(np.float32)
+    return np.ascontiguousarray(np.argsort(d, axis=-1, kind="stable")[..., :k]).astype(np.int64)
+
+
+def structure_features(xyz, idx):
+    """BridgeStructureEncoding.get_structure_features, attention_modules.py:620-687, on the
+    neighbourhoods idx [B,N,k] of xyz [B,N,3] -> (feat [B,N,13], rel [B,N,k,3]) fp32."""
+    xyz, idx = _f32(xyz), _i64(idx)
+    B, N, k = idx.shape
+    rel = (index_points(xyz, idx) - xyz[:, :, None, :]).astype(np.float32)      # :595-600
+    second = (np.einsum("bnka,bnkc->bnac", rel, rel) / np.float32(k - 1)).astype(np.float32)
+    ev = np.linalg.eigvalsh(second).astype(np.float32)                           # ascending, :634
+    den = ev[..., 0] + np.float32(1e-8)
+    f = np.empty((B, N, 13), np.float32)
+    f[..., 0] = (ev[..., 0] - ev[..., 1]) / den
+    f[..., 1] = (ev[..., 1] - ev[..., 2]) / den
+    f[..., 2] = ev[..., 2] / den
+    mean = rel.mean(axis=2, keepdims=True)
+    spread = np.sqrt(((rel - mean) ** 2).sum(-1))                                # :646-647
+    f[..., 3] = spread.max(-1)
+    f[..., 4] = spread.mean(-1)
+    f[..., 5] = spread.std(-1, ddof=1)
+    unit = rel / (np.sqrt((rel ** 2).sum(-1, keepdims=True)) + np.float32(1e-8))  # :657
+    f[..., 6] = np.einsum("bnja,bnla->bnjl", unit, unit).mean(axis=(-1, -2))     # :658-662
+    z = rel[..., 2]
+    f[..., 7] = z.std(-1, ddof=1)
+    f[..., 8] = z.max(-1) - z.min(-1)
+    f[..., 9:12] = mean[:, :, 0, :]
+    f[..., 12] = np.sqrt((rel.std(axis=2, ddof=1) ** 2).sum(-1))                 # :680
+    return f, rel

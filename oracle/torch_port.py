@@ -200,6 +200,80 @@ def dgcnn(model, xyz, colors=None):
     return model.point_conv(torch.cat([local_n, g.expand(-1, -1, N)], dim=1)).transpose(1, 2)
 
 
+# ----------------------------------------------------------------------------- bridge encoders
+def neighbourhood_descriptor(rel):
+    """BridgeStructureEncoding.get_structure_features, attention_modules.py:620-687, with the same
+    ATen operations: rel [B,N,k,3] -> [B,N,13]."""
+    B, N, k, _ = rel.shape
+    flat = rel.reshape(B * N, k, 3)
+    second = torch.bmm(flat.transpose(1, 2), flat) / (k - 1)                       # :631
+    ev = torch.linalg.eigh(second)[0].view(B, N, 3)                                # ascending
+    shape3 = torch.stack([(ev[..., 0] - ev[..., 1]) / (ev[..., 0] + 1e-8),
+                          (ev[..., 1] - ev[..., 2]) / (ev[..., 0] + 1e-8),
+                          ev[..., 2] / (ev[..., 0] + 1e-8)], dim=-1)               # :637-641
+    spread = torch.norm(rel - rel.mean(dim=2, keepdim=True), dim=-1)               # :646-647
+    stats3 = torch.stack([spread.max(dim=-1)[0], spread.mean(dim=-1), spread.std(dim=-1)], dim=-1)
+    unit = (rel / (torch.norm(rel, dim=-1, keepdim=True) + 1e-8)).reshape(B * N, k, 3)
+    cosine = torch.bmm(unit, unit.transpose(1, 2)).view(B, N, k, k).mean(dim=(-1, -2))  # :657-662
+    z = rel[..., 2]
+    z2 = torch.stack([z.std(dim=-1), z.max(dim=-1)[0] - z.min(dim=-1)[0]], dim=-1)  # :665-668
+    return torch.cat([shape3, stats3, cosine.unsqueeze(-1), z2, rel.mean(dim=2),
+                      torch.norm(rel.std(dim=2), dim=-1, keepdim=True)], dim=-1)   # :674-681
+
+
+def cdist_neighbours(xyz, k):
+    """torch.cdist + topk(largest=False), attention_modules.py:584-586 -> [B,N,k] int64."""
+    return torch.cdist(xyz, xyz).topk(k, dim=-1, largest=False)[1]
+
+
+def structure_encoding(mod, xyz):
+    """BridgeStructureEncoding.forward, attention_modules.py:577-618 -> [B,channels,N]."""
+    B, N, _ = xyz.shape
+    k = min(mod.k, N)
+    grid = torch.floor(xyz / mod.grid_size) * mod.grid_size
+    absolute = torch.cat([f(grid * w) for w in mod.freqs for f in (torch.sin, torch.cos)], dim=-1)
+    idx = cdist_neighbours(xyz, k)
+    rel = take_rows(xyz, idx) - xyz.unsqueeze(2)
+    desc = neighbourhood_descriptor(rel)
+    x = torch.cat([absolute.unsqueeze(2).expand(-1, -1, k, -1), rel,
+                   desc.unsqueeze(2).expand(-1, -1, k, -1)], dim=-1).permute(0, 3, 1, 2)
+    return mod.structure_mlp(x).max(dim=-1)[0]
+
+
+def geometric_extraction(mod, x, xyz):
+    """GeometricFeatureExtraction.forward, attention_modules.py:253-269."""
+    return mod.mlp(torch.cat([x, structure_encoding(mod.br_pos, xyz)], dim=1))
+
+
+def colour_extraction(mod, colors, xyz):
+    """ColorFeatureExtraction.forward, attention_modules.py:718-753 (its cdist + topk + gather,
+    :736-743, are executed for their cost and, as there, not used)."""
+    feat = mod.color_mlp(colors)
+    B, _, N = feat.shape
+    idx = cdist_neighbours(xyz, 16)
+    take_rows(feat.transpose(1, 2), idx)
+    local = feat * mod.color_attention(feat)
+    return local * mod.color_context(feat)
+
+
+def bridgeseg(model, xyz, colors):
+    """EnhancedPointNet2.forward, models/model.py:113-147, on the product's container."""
+    pos = structure_encoding(model.bri_enc, xyz)
+    col = colour_extraction(model.color_encoder, colors.transpose(1, 2), xyz)
+    pts = model.feature_fusion.fusion_mlp(torch.cat([pos, col], dim=1))
+    l1_xyz, l1 = _sa(model.sa1, xyz, pts)
+    l2_xyz, l2 = _sa(model.sa2, l1_xyz, l1)
+    l2 = geometric_extraction(model.geometric2, l2, l2_xyz)
+    l3_xyz, l3 = _sa(model.sa3, l2_xyz, l2)
+    l3 = geometric_extraction(model.geometric3, l3, l3_xyz)
+    l2 = _fp(model.fp3, l2_xyz, l3_xyz, l2, l3)
+    l1 = _fp(model.fp2, l1_xyz, l2_xyz, l1, l2)
+    l0 = _fp(model.fp1, xyz, l1_xyz, pts, l1)
+    n = l0.shape[2]
+    fused = torch.cat([conv(F.interpolate(f, size=n)) for f, conv in zip([l2, l1, l0], model.fusion.convs)], dim=1)
+    return model.final_fusion(fused)
+
+
 def run(model, xyz, colors):
     """Forward the product's container `model` (on CPU) through the ATen port."""
     name = type(model).__name__
@@ -209,4 +283,6 @@ def run(model, xyz, colors):
         return pointnet2_msg(model, xyz, colors)
     if name == "DGCNN":
         return dgcnn(model, xyz, colors)
+    if name == "EnhancedPointNet2":
+        return bridgeseg(model, xyz, colors)
     raise TypeError(f"no CPU port for {name}")

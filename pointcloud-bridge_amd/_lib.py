@@ -26,6 +26,7 @@ SIGNATURES = {
     "pcb_interpolate": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "pcb_interpolate_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "pcb_knn": [_p, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_structure_features": [_p, _p, _i, _i, _i, _p, _p, _p],
     "pcb_edge_features": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_edge_features_bwd": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_colstats_bf16": [_p, _l, _i, _p, _p],

@@ -11,6 +11,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import rowmlp
+from .attention_modules import (BridgeStructureEncoding, ColorFeatureExtraction, CompositeFeatureFusion,
+                                GeometricFeatureExtraction)
 from .pointnet2_utils import (EnhancedFeaturePropagation, FeaturePropagation, MultiScaleSetAbstraction,
                               SetAbstraction, _channels_last, _seq_rows, prefetch_sampling)
 
@@ -188,6 +190,59 @@ class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):
         l0 = self.fp1(xyz, l1_xyz, feats, l1)
         fused = self.fusion([l2, l1, l0])  # [B,N,384] channels-last
         B, N, _ = fused.shape
+        ff = self.final_fusion
+        x = rowmlp.conv_bn_act(ff[0], ff[1], fused.view(B * N, -1))
+        logits = rowmlp.conv_rows(ff[4], ff[3](x), torch.float32)
+        return logits.view(B, N, -1).transpose(1, 2)
+
+
+class EnhancedPointNet2(_SamplingPrefetchMixin, nn.Module):
+    """The reference's BridgeSeg network, models/model.py:58-147, whole: structure and colour encoders
+    in front (bri_enc, color_encoder, feature_fusion), MSG encoder, GeometricFeatureExtraction after
+    sa2 / sa3 (geometric1 is constructed and, as in the reference :130, not called), EFP decoder,
+    multi-scale fusion, final_fusion head.  `cls_head` exists only for its state_dict keys (:100-111).
+    forward(xyz [B,N,3], features [B,N,3]) -> logits [B,num_classes,N].
+    """
+
+    def __init__(self, num_classes=5):
+        super().__init__()
+        input_ch = 3
+        self.bri_enc = BridgeStructureEncoding(input_ch, 32, 4)
+        self.color_encoder = ColorFeatureExtraction(3, 6)
+        self.feature_fusion = CompositeFeatureFusion(input_ch, 6)
+        self.sa1 = MultiScaleSetAbstraction(*_MSG_ENCODER[0])
+        self.sa2 = MultiScaleSetAbstraction(*_MSG_ENCODER[1])
+        self.sa3 = MultiScaleSetAbstraction(*_MSG_ENCODER[2])
+        self.geometric1 = GeometricFeatureExtraction(128 * 2)
+        self.geometric2 = GeometricFeatureExtraction(256 * 2)
+        self.geometric3 = GeometricFeatureExtraction(512 * 2)
+        self.fp3 = EnhancedFeaturePropagation(1536, [1024, 256])
+        self.fp2 = EnhancedFeaturePropagation(512, [256, 256])
+        self.fp1 = EnhancedFeaturePropagation(256 + input_ch, [256, 128])
+        self.fusion = MultiScaleFeatureFusion([256, 256, 128], 128)
+        self.final_fusion = nn.Sequential(
+            nn.Conv1d(384, 128, 1), nn.BatchNorm1d(128), nn.ReLU(), nn.Dropout(0.5),
+            nn.Conv1d(128, num_classes, 1))
+        self.num_classes = num_classes
+        self.cls_head = nn.Sequential(
+            nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Dropout(0.5),
+            nn.Linear(512, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+            nn.Linear(256, num_classes))
+
+    def forward(self, xyz, features=None):
+        B, N, _ = xyz.shape
+        pos = self.bri_enc.rows(xyz)                                              # :119
+        col = self.color_encoder.rows(features.float().reshape(B * N, -1), B, N)  # :122
+        fused_in = self.feature_fusion.rows(pos, col).view(B, N, -1).transpose(1, 2)  # :123
+        l1_xyz, l1 = self.sa1(xyz, fused_in)
+        l2_xyz, l2 = self.sa2(l1_xyz, l1)
+        l2 = self.geometric2(l2, l2_xyz)                                          # :133
+        l3_xyz, l3 = self.sa3(l2_xyz, l2)
+        l3 = self.geometric3(l3, l3_xyz)                                          # :136
+        l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
+        l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
+        l0 = self.fp1(xyz, l1_xyz, fused_in, l1)
+        fused = self.fusion([l2, l1, l0])
         ff = self.final_fusion
         x = rowmlp.conv_bn_act(ff[0], ff[1], fused.view(B * N, -1))
         logits = rowmlp.conv_rows(ff[4], ff[3](x), torch.float32)

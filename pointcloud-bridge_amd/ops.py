@@ -228,6 +228,27 @@ def knn(x_bnd, k):
     return out
 
 
+def structure_features(xyz, idx, with_offsets=True):
+    """Neighbourhood descriptor of BridgeStructureEncoding (attention_modules.py:595-603, :620-687):
+    xyz [B,N,3], idx [B,N,k] int64 -> (feat [B,N,13], rel [B,N,k,3] or None), fp32, no gradient
+    (both are functions of the coordinates only)."""
+    _need_cuda(xyz, idx)
+    x = _xyz(xyz, "xyz")
+    nb = _i64c(idx, "idx")
+    B, N, _ = x.shape
+    if nb.dim() != 3 or nb.shape[0] != B or nb.shape[1] != N:
+        raise ValueError(f"idx must be [B,N,k] for xyz {tuple(x.shape)}, got {tuple(nb.shape)}")
+    k = nb.shape[2]
+    if not 2 <= k <= 32:
+        raise ValueError(f"structure_features supports 2 <= k <= 32 (k={k})")
+    feat = torch.empty(B, N, 13, dtype=torch.float32, device=x.device)
+    rel = torch.empty(B, N, k, 3, dtype=torch.float32, device=x.device) if with_offsets else None
+    with torch.cuda.device(x.device):
+        _launch("pcb_structure_features", B * N * k, x.data_ptr(), nb.data_ptr(), B, N, k,
+                feat.data_ptr(), 0 if rel is None else rel.data_ptr())
+    return feat, rel
+
+
 # --------------------------------------------------------------------------------------------
 # differentiable ops
 # --------------------------------------------------------------------------------------------

@@ -81,3 +81,59 @@ def test_port_dgcnn_matches_reference():
     le, lt, loss = _run(model, gg, 2)
     np.testing.assert_allclose(le.numpy(), g["k20_logits_eval"], rtol=1e-5, atol=1e-5)
     assert abs(loss - float(g["k20_loss"])) < 1e-5
+
+
+# ------------------------------------------------------------------ bridge encoders (row f1)
+@pytest.mark.parametrize("k", [16, 32])
+def test_descriptor_oracle_matches_reference(k):
+    g = load_golden("bridge_encoders")
+    ref_idx = g[f"idx{k}"].astype(np.int64)
+    feat, _ = orc.structure_features(g["xyz"], ref_idx)
+    # eigenvalue ratios carry the conditioning of the smallest eigenvalue; the rest is plain fp32
+    np.testing.assert_allclose(feat[..., :3], g[f"desc{k}"][..., :3], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(feat[..., 3:], g[f"desc{k}"][..., 3:], rtol=2e-5, atol=2e-6)
+    # neighbour SETS: the reference's cdist + topk, its numpy restatement, and the expansion-formula
+    # kNN the product uses (pcb_knn's oracle) agree on this cloud
+    want = np.sort(ref_idx, axis=-1)
+    assert np.array_equal(np.sort(orc.cdist_knn(g["xyz"], k), axis=-1), want)
+    assert np.array_equal(np.sort(orc.knn(g["xyz"], k), axis=-1), want)
+    port_desc = port.neighbourhood_descriptor(port.take_rows(t(g["xyz"]), t(ref_idx)) - t(g["xyz"]).unsqueeze(2))
+    np.testing.assert_allclose(port_desc.numpy(), g[f"desc{k}"], rtol=1e-5, atol=1e-6)
+
+
+def _weighted_backward(mod, out):
+    mod.zero_grad()
+    (out * torch.linspace(-1, 1, out.numel()).view_as(out)).sum().backward()
+    return np.array([float(p.grad.norm()) for p in mod.parameters()])
+
+
+def test_port_bridge_encoders_match_reference():
+    from pointcloud_bridge_amd.models import attention_modules as am
+    g = load_golden("bridge_encoders")
+    xyz = t(g["xyz"])
+
+    def check(tag, ctor, fn, *inputs):
+        torch.manual_seed(int(g["init_seed"]))
+        mod = ctor()
+        for mode in ("eval", "train"):
+            mod.train(mode == "train")
+            out = fn(mod, *inputs)
+            np.testing.assert_allclose(out.detach().numpy(), g[f"{tag}_{mode}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(_weighted_backward(mod, out), g[f"{tag}_grad_norms"], rtol=1e-4, atol=1e-6)
+
+    check("enc", lambda: am.BridgeStructureEncoding(3, 32, 4), port.structure_encoding, xyz)
+    check("geo", lambda: am.GeometricFeatureExtraction(32), port.geometric_extraction, t(g["geo_x"]), xyz)
+    check("col", lambda: am.ColorFeatureExtraction(3, 6), port.colour_extraction, t(g["colors"]), xyz)
+    check("fus", lambda: am.CompositeFeatureFusion(3, 6),
+          lambda m, s, c: m.fusion_mlp(torch.cat([s, c], dim=1)), t(g["fus_s"]), t(g["fus_c"]))
+
+
+def test_port_bridgeseg_matches_reference():
+    from pointcloud_bridge_amd.models.containers import EnhancedPointNet2
+    g = load_golden("model_bridgeseg")
+    torch.manual_seed(int(g["init_seed"]))
+    model = EnhancedPointNet2(5)
+    le, lt, loss = _run(model, g, 1)
+    np.testing.assert_allclose(le.numpy(), g["logits_eval"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lt.detach().numpy(), g["logits_train"], rtol=1e-5, atol=1e-5)
+    assert abs(loss - float(g["loss"])) < 1e-5
