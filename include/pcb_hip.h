@@ -164,6 +164,41 @@ int pcb_structure_features(const float *xyz, const int64_t *idx, int B, int N, i
                            float *rel, void *stream);
 
 /*
+ * Neighbourhood MLP.  Replaces BridgeStructureEncoding.structure_mlp applied to the expanded
+ * [B, 6*freq+3+13, N, k] tensor, models/attention_modules.py:548-553 and :606-616
+ * (Conv2d 1x1 -> BatchNorm2d -> ReLU -> Conv2d 1x1 -> max over k), with the first convolution
+ * split by input block: base [P,C] = bias + W[:, per-point channels] . per-point features (the
+ * caller's product, P = B*N points), and per neighbour only  Wr [C,3] . rel[i,j,:]:
+ *     y1 = base[i] + Wr.rel[i,j]   z = relu(scale*y1 + shift)   out[i] = max_j (W2.z + b2)
+ * All fp32, channels-last; 1 <= C <= 16, 1 <= k <= 255.  Training-mode sequence:
+ *   pcb_nbr_mlp_stats    -> sums [parts][2][C] (sum y1, sum y1^2), parts = pcb_nbr_mlp_partials(P)
+ *   pcb_bn_finalize(sums, parts, rows = P*k, ...) -> scale, shift, mean, invstd (+ running stats)
+ *   pcb_nbr_mlp_forward  -> out [P,C], arg [P,C] uint8 (winning neighbour per channel)
+ * Backward (dout [P,C]):
+ *   pcb_nbr_mlp_backward_reduce -> sums [parts][2][C] (sum du, sum du*xhat; du = gradient at the
+ *        BatchNorm output behind the ReLU mask), dw2 [parts][C][C+1] (dW2 | db2 partial sums)
+ *   pcb_bn_bwd_finalize(sums, parts, rows = P*k, ...) -> p, q, dgamma, dbeta
+ *   pcb_nbr_mlp_backward_apply  -> dbase [P,C] (sum_j dy1), dwr [parts][C][3] (partials of
+ *        sum_ij dy1 (x) rel), with dy1 = scale*du + p*y1 + q
+ * The caller adds the `parts` slabs of dw2 / dwr (they are written, not accumulated).
+ */
+int pcb_nbr_mlp_partials(long points);
+int pcb_nbr_mlp_stats(const float *base, const float *rel, long P, int k, int C, const float *wr,
+                      float *sums, void *stream);
+int pcb_nbr_mlp_forward(const float *base, const float *rel, long P, int k, int C, const float *wr,
+                        const float *scale, const float *shift, const float *w2, const float *b2,
+                        float *out, unsigned char *arg, void *stream);
+int pcb_nbr_mlp_backward_reduce(const float *base, const float *rel, long P, int k, int C,
+                                const float *wr, const float *scale, const float *shift,
+                                const float *mean, const float *invstd, const float *w2,
+                                const float *dout, const unsigned char *arg, float *sums, float *dw2,
+                                void *stream);
+int pcb_nbr_mlp_backward_apply(const float *base, const float *rel, long P, int k, int C,
+                               const float *wr, const float *scale, const float *shift, const float *p,
+                               const float *q, const float *w2, const float *dout,
+                               const unsigned char *arg, float *dbase, float *dwr, void *stream);
+
+/*
  * EdgeConv edge features.  Replaces the gather/repeat/cat of DGCNN.get_graph_feature,
  * models/DGCNN.py:90-107: out[b,n,j,:] = cat(x[b,idx[b,n,j]] - x[b,n], x[b,n]).
  *   x [B,N,D], idx [B,N,k] int64, out [B,N,k,2D]   (channels-last; the reference's [B,2D,N,k]

@@ -27,6 +27,11 @@ SIGNATURES = {
     "pcb_interpolate_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "pcb_knn": [_p, _i, _i, _i, _i, _p, _p, _p],
     "pcb_structure_features": [_p, _p, _i, _i, _i, _p, _p, _p],
+    "pcb_nbr_mlp_partials": [_l],
+    "pcb_nbr_mlp_stats": [_p, _p, _l, _i, _i, _p, _p, _p],
+    "pcb_nbr_mlp_forward": [_p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "pcb_nbr_mlp_backward_reduce": [_p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "pcb_nbr_mlp_backward_apply": [_p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "pcb_edge_features": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_edge_features_bwd": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_colstats_bf16": [_p, _l, _i, _p, _p],

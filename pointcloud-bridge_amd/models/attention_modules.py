@@ -14,7 +14,9 @@ What changes underneath:
     one kernel (`pcb_structure_features`);
   * the first 1x1 convolution of structure_mlp is split by input block: the 37 per-point channels
     (absolute encoding, structure descriptor) are multiplied once per point, only the 3 offset
-    channels once per neighbour -- [B,N,k,40] is never built;
+    channels once per neighbour -- [B,N,k,40] is never built, and neither are the [B,C,N,k]
+    activations: BatchNorm, ReLU, the second convolution and the max over k run inside
+    ..nbrmlp (csrc/nbrmlp.hip) with the rows in registers;
   * ColorFeatureExtraction's neighbour search is dropped: the reference computes it and never uses the
     result (:736-743), so the output is identical without it.
 The narrow (3..40 channel) layers run as fp32 torch ops in both precision modes; the wide pointwise
@@ -24,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops, rowmlp
+from .. import nbrmlp, ops, rowmlp
 from .pointnet2_utils import _channels_last, _seq_rows
 
 
@@ -103,10 +105,13 @@ class BridgeStructureEncoding(nn.Module):
         w = conv0.weight.view(self.channels, self.total_dim)
         # conv0 over cat(abs, rel, struct) (:606-614) = per-point part + per-neighbour part
         base = F.linear(per_point.view(B * N, -1), torch.cat([w[:, :a], w[:, a + 3:]], dim=1), conv0.bias)
-        y = (rel.view(B * N, k, 3) @ w[:, a:a + 3].t()) + base.unsqueeze(1)
-        y = F.relu(rowmlp._bn_rows_fp32(bn, y.view(B * N * k, self.channels)))
-        y = _rows_conv(conv1, y)
-        return y.view(B * N, k, self.channels).max(dim=1)[0]          # :616
+        if isinstance(bn, nn.SyncBatchNorm) or self.channels > 16 or k > 255:
+            # statistics shared across ranks / widths beyond the fused kernel: the same algebra as
+            # torch ops on the materialised [P*k, C] rows
+            y = (rel.view(B * N, k, 3) @ w[:, a:a + 3].t()) + base.unsqueeze(1)
+            y = F.relu(rowmlp._bn_rows_fp32(bn, y.view(B * N * k, self.channels)))
+            return _rows_conv(conv1, y).view(B * N, k, self.channels).max(dim=1)[0]
+        return nbrmlp.neighbour_mlp(base, rel.view(B * N, k, 3), w[:, a:a + 3], bn, conv1)  # :614-616
 
     def forward(self, xyz):
         B, N, _ = xyz.shape

@@ -173,3 +173,49 @@ def test_bridgeseg_bf16_step_tracks_fp32():
                 assert p.grad is not None and torch.isfinite(p.grad).all(), name
     finally:
         rowmlp.set_precision("fp32")
+
+
+@pytest.mark.parametrize("P,k,C", [(5000, 32, 3), (777, 16, 16), (300, 7, 5), (70000, 3, 1)])
+@pytest.mark.parametrize("training", [True, False])
+def test_neighbour_mlp_kernels_match_torch_composition(P, k, C, training):
+    """pcb_nbr_mlp_* (through the autograd wrapper) against the same layers as fp64 torch ops on
+    the materialised [P*k, C] rows: output, running statistics, every gradient."""
+    import torch.nn as nn
+    from pointcloud_bridge_amd import nbrmlp
+    g = torch.Generator().manual_seed(P + k + C)
+    base0 = torch.randn(P, C, generator=g).cuda()
+    rel = (0.3 * torch.randn(P, k, 3, generator=g)).cuda()
+    wr0 = torch.randn(C, 3, generator=g).cuda()
+    torch.manual_seed(5)
+    bns = [nn.BatchNorm2d(C).cuda() for _ in range(2)]
+    convs = [nn.Conv2d(C, C, 1).cuda() for _ in range(2)]
+    with torch.no_grad():
+        for m in (bns[0], convs[0]):
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape, generator=g).cuda() * 0.5 + (1.0 if p.dim() == 1 else 0.0))
+        bns[0].running_mean.normal_(generator=None)
+        bns[0].running_var.uniform_(0.5, 2.0)
+        bns[1].load_state_dict(bns[0].state_dict())
+        convs[1].load_state_dict(convs[0].state_dict())
+    weight = torch.linspace(-0.5, 1, P * C, device="cuda").view(P, C)  # asymmetric: no gradient sums to ~0
+    res = []
+    for which in (0, 1):
+        bn, conv = bns[which].train(training), convs[which]
+        base, wr = base0.clone().requires_grad_(True), wr0.clone().requires_grad_(True)
+        if which == 0:
+            out = nbrmlp.neighbour_mlp(base, rel, wr, bn, conv)
+        else:
+            bn, conv = bn.double(), conv.double()  # the yardstick in fp64
+            base, wr = base0.double().requires_grad_(True), wr0.double().requires_grad_(True)
+            y = (rel.double() @ wr.t() + base.unsqueeze(1)).view(P * k, C)
+            y = F.relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps))
+            out = F.linear(y, conv.weight.view(C, C), conv.bias).view(P, k, C).max(dim=1)[0]
+        (out * weight).sum().backward()
+        res.append((out.detach(), base.grad, wr.grad, bn.weight.grad, bn.bias.grad, conv.weight.grad.view(C, C),
+                    conv.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    names = ("out", "dbase", "dwr", "dgamma", "dbeta", "dw2", "db2", "running_mean", "running_var")
+    for name, a, b in zip(names, res[0], res[1]):
+        err = float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-12))
+        assert err < 2e-4, (name, err)
+    if training:
+        assert int(bns[0].num_batches_tracked) == 1
