@@ -199,6 +199,23 @@ int pcb_nbr_mlp_backward_apply(const float *base, const float *rel, long P, int 
                                const unsigned char *arg, float *dbase, float *dwr, void *stream);
 
 /*
+ * Narrow pointwise layers on fp32 rows.  Replace the Conv1d / Conv2d 1x1 layers with 3..40 channels
+ * of the bridge encoders, models/attention_modules.py:548-553 (per-point block), :696-716, :759-764
+ * (N = 3..16 output columns: no MFMA tile to fill; they are HBM streams of 4*(Ci+Co) bytes per row).
+ *   pcb_rows_linear_f32        y [P,Co] = x [P,Ci] . w[Co,Ci]^T + bias[Co] (bias may be NULL)
+ *   pcb_rows_linear_dgrad_f32  dx [P,Ci] = dy [P,Co] . w[Co,Ci]
+ *   pcb_rows_linear_wgrad_f32  partials [parts][Co][Ci+1]: per-block sums of dy^T x, last column = sum dy
+ *                              (bias gradient); parts = pcb_rows_linear_wgrad_partials(P); the caller adds
+ *                              the slabs.  1 <= Ci, Co <= 64.
+ */
+int pcb_rows_linear_f32(const float *x, const float *w, const float *bias, long P, int Ci, int Co, float *y,
+                        void *stream);
+int pcb_rows_linear_dgrad_f32(const float *dy, const float *w, long P, int Ci, int Co, float *dx, void *stream);
+int pcb_rows_linear_wgrad_partials(long P);
+int pcb_rows_linear_wgrad_f32(const float *dy, const float *x, long P, int Ci, int Co, float *partials,
+                              void *stream);
+
+/*
  * EdgeConv edge features.  Replaces the gather/repeat/cat of DGCNN.get_graph_feature,
  * models/DGCNN.py:90-107: out[b,n,j,:] = cat(x[b,idx[b,n,j]] - x[b,n], x[b,n]).
  *   x [B,N,D], idx [B,N,k] int64, out [B,N,k,2D]   (channels-last; the reference's [B,2D,N,k]

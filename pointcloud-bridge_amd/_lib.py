@@ -27,6 +27,10 @@ SIGNATURES = {
     "pcb_interpolate_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "pcb_knn": [_p, _i, _i, _i, _i, _p, _p, _p],
     "pcb_structure_features": [_p, _p, _i, _i, _i, _p, _p, _p],
+    "pcb_rows_linear_f32": [_p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_rows_linear_dgrad_f32": [_p, _p, _l, _i, _i, _p, _p],
+    "pcb_rows_linear_wgrad_partials": [_l],
+    "pcb_rows_linear_wgrad_f32": [_p, _p, _l, _i, _i, _p, _p],
     "pcb_nbr_mlp_partials": [_l],
     "pcb_nbr_mlp_stats": [_p, _p, _l, _i, _i, _p, _p, _p],
     "pcb_nbr_mlp_forward": [_p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -19,19 +19,29 @@ What changes underneath:
     ..nbrmlp (csrc/nbrmlp.hip) with the rows in registers;
   * ColorFeatureExtraction's neighbour search is dropped: the reference computes it and never uses the
     result (:736-743), so the output is identical without it.
-The narrow (3..40 channel) layers run as fp32 torch ops in both precision modes; the wide pointwise
+The narrow (3..40 channel) layers stay fp32 in both precision modes: their 1x1 convolutions are
+..rowsf32 (csrc/tinylin.hip; as GEMMs they have 3..16 columns and the library kernels picked for
+them take 0.2-0.6 ms each), BatchNorm / ReLU / Sigmoid on them are ATen row ops.  The wide pointwise
 layers of GeometricFeatureExtraction go through ..rowmlp like the SA/FP stacks.  GPU only.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import nbrmlp, ops, rowmlp
+from .. import nbrmlp, ops, rowmlp, rowsf32
 from .pointnet2_utils import _channels_last, _seq_rows
 
 
+def _rows_linear(x, w, b):
+    """x [R,Ci] . w[Co,Ci]^T + b: the narrow-layer kernels for many rows, ATen for a handful (the
+    per-scene context vector of ColorFeatureExtraction)."""
+    if x.shape[0] >= 1024 and max(w.shape) <= rowsf32.MAX_CHANNELS:
+        return rowsf32.rows_linear(x, w, b)
+    return F.linear(x, w, b)
+
+
 def _rows_conv(conv, x):
-    return F.linear(x, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+    return _rows_linear(x, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
 
 
 def _rows_seq_f32(seq, x):
@@ -104,7 +114,7 @@ class BridgeStructureEncoding(nn.Module):
         a = self.abs_pos_dim
         w = conv0.weight.view(self.channels, self.total_dim)
         # conv0 over cat(abs, rel, struct) (:606-614) = per-point part + per-neighbour part
-        base = F.linear(per_point.view(B * N, -1), torch.cat([w[:, :a], w[:, a + 3:]], dim=1), conv0.bias)
+        base = _rows_linear(per_point.view(B * N, -1), torch.cat([w[:, :a], w[:, a + 3:]], dim=1), conv0.bias)
         if isinstance(bn, nn.SyncBatchNorm) or self.channels > 16 or k > 255:
             # statistics shared across ranks / widths beyond the fused kernel: the same algebra as
             # torch ops on the materialised [P*k, C] rows

@@ -219,3 +219,29 @@ def test_neighbour_mlp_kernels_match_torch_composition(P, k, C, training):
         assert err < 2e-4, (name, err)
     if training:
         assert int(bns[0].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("P,Ci,Co,bias", [(262144, 37, 3, True), (5000, 3, 16, True), (1025, 16, 6, False),
+                                           (777, 64, 64, True), (4096, 9, 3, True), (300, 1, 1, False)])
+def test_rows_linear_kernels_match_fp64(P, Ci, Co, bias):
+    """pcb_rows_linear_f32 / _dgrad / _wgrad through the autograd wrapper against fp64 torch."""
+    from pointcloud_bridge_amd import rowsf32
+    g = torch.Generator().manual_seed(P + Ci + Co)
+    x0 = torch.randn(P, Ci, generator=g).cuda()
+    w0 = torch.randn(Co, Ci, generator=g).cuda()
+    b0 = torch.randn(Co, generator=g).cuda() if bias else None
+    gy = (torch.randn(P, Co, generator=g) + 0.3).cuda()
+    x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    b = b0.clone().requires_grad_(True) if bias else None
+    y = rowsf32.rows_linear(x, w, b)
+    y.backward(gy)
+    xd, wd = x0.double().requires_grad_(True), w0.double().requires_grad_(True)
+    bd = b0.double().requires_grad_(True) if bias else None
+    yd = F.linear(xd, wd, bd)
+    yd.backward(gy.double())
+    pairs = [("y", y.detach(), yd.detach()), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad)]
+    if bias:
+        pairs.append(("db", b.grad, bd.grad))
+    for name, a, ref in pairs:
+        err = float((a.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, (name, err)
