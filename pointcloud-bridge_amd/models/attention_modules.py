@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import nbrmlp, ops, rowmlp, rowsf32
-from .pointnet2_utils import _channels_last, _seq_rows
+from .pointnet2_utils import _channels_last, _seq_rows, side_stream
 
 
 def _rows_linear(x, w, b):
@@ -58,6 +58,9 @@ def _rows_seq_f32(seq, x):
         else:
             raise TypeError(f"unsupported layer in pointwise stack: {type(m).__name__}")
     return x
+
+
+_geometry = {}  # parked results of BridgeStructureEncoding.prefetch, keyed by tensor identity
 
 
 class BridgeStructureEncoding(nn.Module):
@@ -101,15 +104,48 @@ class BridgeStructureEncoding(nn.Module):
         feat, _ = ops.structure_features(cloud.contiguous(), idx, with_offsets=False)
         return feat[:, 0].reshape(B, N, 13)
 
+    def geometry(self, xyz):
+        """Everything that depends on the coordinates only: per-point channels [B,N,6F+13] (absolute
+        encoding, structure descriptor) and the neighbour offsets rel [B,N,k,3].  No gradient."""
+        k = min(self.k, xyz.shape[1])
+        with torch.no_grad():
+            idx = ops.knn(xyz, k)                                       # :584-586
+            struct, rel = ops.structure_features(xyz, idx)             # :595-603
+            per_point = torch.cat([self.compute_absolute_position_encoding(xyz), struct], dim=-1)
+        return per_point, rel
+
+    def _geometry_key(self, xyz):
+        return (xyz.data_ptr(), xyz._version, tuple(xyz.shape), min(self.k, xyz.shape[1]), self.freq_bands,
+                float(self.grid_size))
+
+    def prefetch(self, xyz):
+        """Compute geometry(xyz) of the NEXT batch on the side stream that also carries the FPS
+        pyramid (pointnet2_utils.prefetch_sampling), while the current batch is in its backward
+        pass; rows() picks it up by tensor identity.  Same results, only earlier."""
+        xyz = xyz.float().contiguous()
+        side = side_stream(xyz.device)
+        side.wait_stream(torch.cuda.current_stream())
+        _geometry.clear()
+        with torch.cuda.stream(side):
+            per_point, rel = self.geometry(xyz)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        _geometry[self._geometry_key(xyz)] = (per_point, rel, ev)
+
     def rows(self, xyz):
         """xyz [B,N,3] -> code rows [B*N, channels] (channels-last)."""
         B, N, _ = xyz.shape
         xyz = xyz.float().contiguous()
         k = min(self.k, N)
-        with torch.no_grad():
-            idx = ops.knn(xyz, k)                                       # :584-586
-            struct, rel = ops.structure_features(xyz, idx)             # :595-603
-            per_point = torch.cat([self.compute_absolute_position_encoding(xyz), struct], dim=-1)
+        hit = _geometry.pop(self._geometry_key(xyz), None)
+        if hit is None:
+            per_point, rel = self.geometry(xyz)
+        else:
+            per_point, rel, ev = hit
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            per_point.record_stream(main)
+            rel.record_stream(main)
         conv0, bn, _, conv1 = self.structure_mlp
         a = self.abs_pos_dim
         w = conv0.weight.view(self.channels, self.total_dim)

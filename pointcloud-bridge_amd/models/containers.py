@@ -229,6 +229,13 @@ class EnhancedPointNet2(_SamplingPrefetchMixin, nn.Module):
             nn.Linear(512, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
             nn.Linear(256, num_classes))
 
+    def prefetch(self, xyz):
+        """Coordinate-only work of the NEXT batch on the side stream: the kNN graph + structure
+        descriptor of bri_enc, then the FPS pyramid."""
+        xyz = xyz.contiguous()
+        self.bri_enc.prefetch(xyz)
+        super().prefetch(xyz)
+
     def forward(self, xyz, features=None):
         B, N, _ = xyz.shape
         pos = self.bri_enc.rows(xyz)                                              # :119

@@ -63,13 +63,20 @@ def _key(xyz, npoint):
     return (xyz.data_ptr(), xyz._version, tuple(xyz.shape), int(npoint))
 
 
+def side_stream(device):
+    """The stream the coordinate-only work of the NEXT batch runs on (FPS pyramid here, the
+    neighbourhood geometry of attention_modules.BridgeStructureEncoding)."""
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream(device=device)
+    return _side_stream
+
+
 def prefetch_sampling(xyz, npoints):
     """Compute the FPS pyramid xyz -> npoints[0] -> npoints[1] -> ... on a side stream and park it
     for the next forward pass over these coordinates (SetAbstraction / MultiScaleSetAbstraction pick
     it up by tensor identity).  Call after the forward of the current batch."""
-    global _side_stream
-    if _side_stream is None:
-        _side_stream = torch.cuda.Stream(device=xyz.device)
+    side_stream(xyz.device)
     main = torch.cuda.current_stream()
     _side_stream.wait_stream(main)
     _prefetched.clear()

@@ -245,3 +245,19 @@ def test_rows_linear_kernels_match_fp64(P, Ci, Co, bias):
     for name, a, ref in pairs:
         err = float((a.double() - ref).abs().max() / ref.abs().max())
         assert err < 2e-5, (name, err)
+
+
+def test_bridgeseg_prefetch_gives_identical_results():
+    """Geometry (kNN graph + descriptor) and FPS pyramid computed ahead on the side stream must
+    reproduce the in-line forward bit for bit."""
+    from pointcloud_bridge_amd.models.containers import EnhancedPointNet2
+    g = load_golden("model_bridgeseg")
+    xyz, colors = dev(g["xyz"]), dev(g["colors"])
+    model = build(EnhancedPointNet2, g["init_seed"], 5).eval()
+    with torch.no_grad():
+        torch.manual_seed(3)
+        plain = model(xyz, colors)
+        torch.manual_seed(3)
+        model.prefetch(xyz)   # draws the FPS start indices now, in the same order
+        ahead = model(xyz, colors)
+    assert torch.equal(plain, ahead)
