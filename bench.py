@@ -116,6 +116,9 @@ def main():
                     help="train mode: replay forward+backward as one captured hipGraph instead of launching every "
                          "kernel from the host (measured equal on MI355X: the step is GPU-bound, so off by default; "
                          "pn2_msg / pn2_ssg only)")
+    ap.add_argument("--loss", default="ce", choices=["ce", "bridge"],
+                    help="bridge: BridgeStructureLoss(alpha=80, rel_margin=0.3) of train_MulSca_BriStruNet_CB.py:151-156 "
+                         "(bridgeseg / pn2_msg / pn2_ssg logits [B,C,N])")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="pointwise-MLP arithmetic: bf16 activations (BASELINE config 2) or the fp32 parity mode")
     args = ap.parse_args()
@@ -155,10 +158,21 @@ def main():
     torch.manual_seed(7 + rank)  # CPU generator: FPS start indices
 
     prefetch = (not args.no_prefetch) and hasattr(model, "prefetch")
+    if args.loss == "bridge":
+        if cdim != 1:
+            raise SystemExit("--loss bridge expects [B,C,N] logits (bridgeseg, pn2_msg, pn2_ssg)")
+        from pointcloud_bridge_amd.losses import BridgeStructureLoss
+        crit = BridgeStructureLoss(alpha=80, rel_margin=0.3).to(device)  # train_MulSca_BriStruNet_CB.py:151-156
+
+        def loss_of(logits):
+            return crit(logits.float(), labels, xyz)
+    else:
+        def loss_of(logits):
+            return loss_fn(logits, labels, cdim)
 
     def train_step():
         bucket.zero()
-        loss = loss_fn(model(xyz, colors), labels, cdim)
+        loss = loss_of(model(xyz, colors))
         if prefetch:
             model.prefetch(xyz)  # sampling pyramid of the next batch, concurrent with this backward
         loss.backward()
@@ -168,7 +182,7 @@ def main():
 
     def infer_step():
         with torch.no_grad():
-            return loss_fn(model(xyz, colors), labels, cdim)
+            return loss_of(model(xyz, colors))
 
     if args.mode == "infer":
         model.eval()
@@ -190,7 +204,7 @@ def main():
         loss_buf = torch.zeros((), device=device)
 
         def fwd_bwd():
-            loss = loss_fn(model(xyz, colors), labels, cdim)
+            loss = loss_of(model(xyz, colors))
             if static is not None:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
@@ -305,7 +319,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": vs_baseline, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} {'fwd+CE+bwd+grad-allreduce+Adam' if args.mode == 'train' else 'eval-mode forward+CE'}, B={B} scenes/GPU x N={N} pts, "
+            "config": {"workload": f"{args.model} {('fwd+' + ('CE' if args.loss == 'ce' else 'BridgeStructureLoss') + '+bwd+grad-allreduce+Adam') if args.mode == 'train' else 'eval-mode forward+CE'}, B={B} scenes/GPU x N={N} pts, "
                                    f"unit-ball clouds (configs[1] of BASELINE.json)",
                        "scenes_per_gpu": B, "points_per_scene": N, "parallelism": f"dp{world} (scenes sharded)",
                        "loss": float(loss.detach()),

@@ -1,0 +1,67 @@
+"""Training criterion of the reference's BridgeSeg trainer (caller side of the hot path).
+
+`BridgeStructureLoss`: models/model.py:169-260 of the reference, used by
+train_MulSca_BriStruNet_CB.py:151-156,178 as `criterion(outputs, labels, points=points)`: a
+label-smoothed cross entropy whose 5 class weights are raised, per step, where the PREDICTED
+components violate the bridge's vertical order (abutment < girder < deck < parapet).  Same constructor,
+buffer name and result.  The reference decides with Python `if tensor.any()` (one host sync per
+class pair, ~20 per step); here the same conditions multiply the additions as 0/1 tensors, so the
+criterion enqueues without reading anything back.  Plain torch ops on [B,N] masks -- no kernel of its
+own; runs wherever its inputs live.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# (class, classes that must lie below it, classes that must lie above it) -- models/model.py:176-182
+_ORDER = ((1, (), (2, 3, 4)), (2, (1,), (3, 4)), (3, (1, 2), (4,)), (4, (1, 2, 3), ()))
+
+
+class BridgeStructureLoss(nn.Module):
+    def __init__(self, num_classes=5, alpha=20.0, rel_margin=0.2, class_weights=None):
+        super().__init__()
+        self.alpha = alpha
+        self.rel_margin = rel_margin
+        default_weights = torch.tensor([1.5, 1.0, 1.2, 1.5, 1.0])
+        self.base_weights = default_weights if class_weights is None else class_weights
+        self.register_buffer('base_weights_buffer', self.base_weights)
+
+    @staticmethod
+    def _mean_relative_height(points, mask):
+        """models/model.py:189-196: z of the masked points, normalised by the extent of the MASKED
+        cloud (unselected points count as the origin), averaged over the selected points -> [B]."""
+        m = mask.to(points.dtype)
+        masked = points * m.unsqueeze(-1)
+        lo = masked.amin(dim=1, keepdim=True)
+        hi = masked.amax(dim=1, keepdim=True)
+        rel = (masked - lo) / (hi - lo + 1e-7)
+        return (rel[..., 2] * m).sum(dim=1) / m.sum(dim=1).clamp(min=1)
+
+    def forward(self, outputs, labels, points):
+        """outputs [B,5,N] logits, labels [B,N] int64, points [B,N,3] -> scalar loss."""
+        logits = outputs.transpose(1, 2)
+        B = labels.shape[0]
+        with torch.no_grad():
+            preds = torch.argmax(logits, dim=-1)
+            weights = self.base_weights_buffer.to(logits.device).repeat(B, 1)
+            # a class takes part only if SOME scene of the batch carries it in the labels (:208-211,
+            # :230, :240) -- a 0/1 scalar instead of an `if`
+            present = {c: (labels == c).any().to(weights.dtype) for c in (1, 2, 3, 4)}
+            height = {c: self._mean_relative_height(points, preds == c) for c in (1, 2, 3, 4)}  # :213-216
+            cols = [weights[:, c] for c in range(weights.shape[1])]
+            for cid, lower_classes, upper_classes in _ORDER:
+                for low in lower_classes:                                   # 'above' entries, :228-236
+                    v = F.relu(self.rel_margin - (height[cid] - height[low])) * present[low]
+                    cols[cid] = cols[cid] + self.alpha * v
+                    cols[low] = cols[low] + self.alpha * v * 0.5
+                for up in upper_classes:                                    # 'below' entries, :238-246
+                    v = F.relu(self.rel_margin - (height[up] - height[cid])) * present[up]
+                    cols[cid] = cols[cid] + self.alpha * v
+                    cols[up] = cols[up] + self.alpha * v * 0.3
+            cols[0] = cols[0] + self.alpha * (1 - (preds == 0).to(weights.dtype).mean(dim=1))  # :250-251
+            weights = torch.stack(cols, dim=1)
+            freq = torch.bincount(labels.reshape(-1), minlength=5).to(weights.dtype).clamp(min=1)  # :253
+            class_weights = 1 / freq.sqrt()
+            class_weights = class_weights * class_weights.new_tensor([1.0, 2.0, 1.0, 1.0, 2.0])  # :255-256
+            w = weights.mean(dim=0) * class_weights
+        return F.cross_entropy(logits.reshape(-1, 5), labels.reshape(-1), weight=w, label_smoothing=0.2)

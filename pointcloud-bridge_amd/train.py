@@ -8,6 +8,7 @@ the parts of their loops that touch the hot path, with the same hyper-parameters
   * Adam(lr=1e-3, betas=(.9,.999), weight_decay=1e-4)            train_MulSca_PN2.py:125
   * ReduceLROnPlateau(mode='max', factor=0.1, patience=5) on val accuracy      :127, :235
   * CrossEntropyLoss on [B,C,N] logits (PointNet++)              :161
+  * BridgeStructureLoss(logits, labels, points) for BridgeSeg    train_MulSca_BriStruNet_CB.py:151-178 (..losses)
     or on [B*N,C] after a reshape (DGCNN)                        train_DGCNN.py:177-197
   * metrics from a confusion matrix: IoU = diag / (row + col - diag + 1e-6), mIoU = nanmean,
     OA = trace / total                                           inference.py:814-855
@@ -63,8 +64,12 @@ def metrics_from_confusion(cm):
 class Trainer:
     """One model, the reference's optimiser and scheduler, optional data parallelism."""
 
-    def __init__(self, model, num_classes=5, lr=1e-3, weight_decay=1e-4, distributed=False):
+    def __init__(self, model, num_classes=5, lr=1e-3, weight_decay=1e-4, distributed=False, criterion=None):
+        """criterion: None = CrossEntropy (train_MulSca_PN2.py:161, train_DGCNN.py:177-197), or a module
+        called as criterion(logits, labels, points) like losses.BridgeStructureLoss
+        (train_MulSca_BriStruNet_CB.py:151-156, :178)."""
         self.model = model
+        self.criterion = criterion
         self.num_classes = num_classes
         self.channels_last = type(model).__name__ == "DGCNN"  # DGCNN returns [B,N,C] (DGCNN.py:170)
         self.bucket = parallel.FlatGradAllReduce(model.parameters()) if distributed else None
@@ -78,7 +83,10 @@ class Trainer:
         else:
             self.opt.zero_grad(set_to_none=True)
         logits = self.model(batch["points"], batch["colors"])
-        loss = segmentation_loss(logits, batch["labels"], self.channels_last)
+        if self.criterion is not None:
+            loss = self.criterion(logits, batch["labels"], batch["points"])
+        else:
+            loss = segmentation_loss(logits, batch["labels"], self.channels_last)
         loss.backward()
         if self.bucket is not None:
             self.bucket.reduce()

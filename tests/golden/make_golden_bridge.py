@@ -119,7 +119,47 @@ def make_model():
     print("model_bridgeseg", out["loss"], out["logits_train"].shape)
 
 
+def make_loss():
+    """BridgeStructureLoss (models/model.py:169-260) on six small batches that reach every branch:
+    all classes present, a class absent from the labels, a class never predicted, everything
+    predicted 'other', labels all 'other', one class dominating a scene."""
+    from models.model import BridgeStructureLoss as RefLoss
+
+    g = torch.Generator().manual_seed(1)
+    res = {}
+    for case in range(6):
+        B, N = 3, 700
+        out = torch.randn(B, 5, N, generator=g) * 2
+        pts = torch.randn(B, N, 3, generator=g)
+        lab = torch.randint(0, 5, (B, N), generator=g)
+        if case == 1:
+            lab[lab == 3] = 0
+        if case == 2:
+            lab[lab == 1] = 2
+            out[:, 4] -= 100
+        if case == 3:
+            out[:, 1:] -= 100
+        if case == 4:
+            lab[:] = 0
+        if case == 5:
+            out[0, 2] += 100
+            out[1, 4] += 100
+        res[f"c{case}_outputs"], res[f"c{case}_points"], res[f"c{case}_labels"] = out.numpy(), pts.numpy(), lab.numpy()
+        for tag, (alpha, margin) in (("a80", (80, 0.3)), ("a20", (20.0, 0.2))):   # trainer's / default
+            o = out.clone().requires_grad_(True)
+            loss = RefLoss(alpha=alpha, rel_margin=margin)(o, lab, pts)
+            loss.backward()
+            res[f"c{case}_{tag}_loss"] = np.float64(loss.item())
+            res[f"c{case}_{tag}_grad"] = o.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "bridge_loss.npz"), **res)
+    print("bridge_loss.npz", len(res), "arrays")
+
+
 if __name__ == "__main__":
+    if "loss" in sys.argv[1:]:
+        make_loss()
+        sys.exit(0)
     if "model" not in sys.argv[1:]:
         make_encoders()
+        make_loss()
     make_model()

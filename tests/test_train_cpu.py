@@ -1,4 +1,6 @@
 """CPU: host-side pieces of the training harness (metrics as inference.py:814-855 defines them)."""
+import numpy as np
+import pytest
 import torch
 
 from pointcloud_bridge_amd import train
@@ -35,3 +37,20 @@ def test_synthetic_scenes_are_normalised_like_the_dataset():
     b = train.synthetic_scenes(3, 500, seed=1)
     assert b["points"].shape == (3, 500, 3) and b["labels"].max() <= 4
     assert torch.allclose(b["points"].norm(dim=-1).max(dim=1)[0], torch.ones(3), atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,alpha,margin", [("a80", 80, 0.3), ("a20", 20.0, 0.2)])
+def test_bridge_structure_loss_matches_reference(tag, alpha, margin):
+    """losses.BridgeStructureLoss (sync-free restatement) against the reference's criterion
+    (models/model.py:169-260) on the six branch-covering batches of bridge_loss.npz."""
+    from pointcloud_bridge_amd.losses import BridgeStructureLoss
+    from tests.helpers import load_golden
+    g = load_golden("bridge_loss")
+    crit = BridgeStructureLoss(alpha=alpha, rel_margin=margin)
+    assert list(crit.state_dict().keys()) == ["base_weights_buffer"]
+    for case in range(6):
+        out = torch.from_numpy(g[f"c{case}_outputs"]).requires_grad_(True)
+        loss = crit(out, torch.from_numpy(g[f"c{case}_labels"]), torch.from_numpy(g[f"c{case}_points"]))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g[f"c{case}_{tag}_loss"])) <= 1e-6 * abs(float(g[f"c{case}_{tag}_loss"]))
+        np.testing.assert_allclose(out.grad.numpy(), g[f"c{case}_{tag}_grad"], rtol=1e-6, atol=1e-9)
