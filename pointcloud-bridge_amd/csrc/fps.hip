@@ -7,7 +7,10 @@
 //   scan P points per lane -> DPP reduction in the wave -> one LDS slot per wave -> ONE barrier
 //   -> every wave reduces the <=16 slots redundantly (no second barrier; slots are double-buffered).
 // Arithmetic is the reference's: d = (dx*dx + dy*dy) + dz*dz, strict "<" min-update, first index
-// of the maximum.
+// of the maximum.  Clouds above 2048 points run the spatially sorted variant further down, which
+// skips the waves a new centroid provably cannot affect.
+#include <stdlib.h>
+
 #include "pcb_common.h"
 
 namespace {
@@ -103,6 +106,214 @@ __global__ __launch_bounds__(T) void fps_regs_kernel(const float *__restrict__ x
     }
 }
 
+// ---- spatially sorted variant ----------------------------------------------------------------
+// Same arithmetic, same results; the scan of all N points per iteration is what bounds the kernel
+// above (VALU), and most of it is provably idle: a new centroid c can lower the running minimum of a
+// point p only if d(p,c) < run[p].  The workgroup first sorts its cloud along a Morton curve (16^3
+// cells, counting sort in LDS) so that each WAVE owns a compact box of T*P/NW consecutive points.
+// Per iteration a wave evaluates the distance from c to its box with the SAME rounded operations
+// as the point distance -- fl() is monotonic, so box distance <= every point's computed distance --
+// and if that is >= the wave's current maximum of run[], no lane can change: the wave skips the
+// update, the arg-max search and both reductions and re-publishes its cached (maximum, index).
+// Ties are broken on the ORIGINAL indices (kept beside the coordinates), so the output is
+// bit-identical to the unsorted kernel; the order inside a cell is irrelevant to the result.
+constexpr int kCellBits = 4;
+constexpr int kCells = 1 << (3 * kCellBits);
+
+__device__ __forceinline__ int spread3(int v)  // 4 bits -> every third bit
+{
+    return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6);
+}
+__device__ __forceinline__ float wave_minf(float v) { return -wave_max(-v); }
+
+template <int T, int P>
+__global__ __launch_bounds__(T) void fps_sorted_kernel(const float *__restrict__ xyz, int N, int S,
+                                                        const int64_t *__restrict__ start,
+                                                        int64_t *__restrict__ out)
+{
+    constexpr int NW = T / PCB_WAVE;
+    static_assert(kCells % T == 0, "cells per thread");
+    constexpr int CPT = kCells / T;
+    __shared__ float s_stage[T * P];
+    __shared__ int s_hist[kCells];
+    __shared__ float s_box[6][NW];
+    __shared__ int s_scan[NW];
+    __shared__ float s_val[2][NW];
+    __shared__ int s_idx[2][NW];
+
+    const int b = blockIdx.x;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const float *__restrict__ p = xyz + (size_t)b * N * 3;
+    int64_t *__restrict__ o = out + (size_t)b * S;
+
+    float px[P], py[P], pz[P], run[P];
+    int oidx[P];
+    // -- load in the original order, cloud bounding box
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int i = q * T + t;
+        const int ii = i < N ? i : N - 1;
+        px[q] = p[ii * 3 + 0];
+        py[q] = p[ii * 3 + 1];
+        pz[q] = p[ii * 3 + 2];
+        lo[0] = fminf(lo[0], px[q]); hi[0] = fmaxf(hi[0], px[q]);
+        lo[1] = fminf(lo[1], py[q]); hi[1] = fmaxf(hi[1], py[q]);
+        lo[2] = fminf(lo[2], pz[q]); hi[2] = fmaxf(hi[2], pz[q]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = wave_minf(lo[a]), h = wave_max(hi[a]);
+        if (lane == 0) {
+            s_box[a][wave] = l;
+            s_box[3 + a][wave] = h;
+        }
+    }
+    for (int e = t; e < kCells; e += T) s_hist[e] = 0;
+    __syncthreads();
+    float inv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = s_box[a][0], h = s_box[3 + a][0];
+        for (int w = 1; w < NW; ++w) {
+            l = fminf(l, s_box[a][w]);
+            h = fmaxf(h, s_box[3 + a][w]);
+        }
+        lo[a] = l;
+        inv[a] = h > l ? (float)(1 << kCellBits) / (h - l) : 0.0f;
+    }
+    // -- counting sort by Morton cell: rank inside the cell from the histogram atomics
+    int slot[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int i = q * T + t;
+        const int cx = min((1 << kCellBits) - 1, max(0, (int)((px[q] - lo[0]) * inv[0])));
+        const int cy = min((1 << kCellBits) - 1, max(0, (int)((py[q] - lo[1]) * inv[1])));
+        const int cz = min((1 << kCellBits) - 1, max(0, (int)((pz[q] - lo[2]) * inv[2])));
+        const int code = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
+        // low 12 bits: cell, high bits: rank in the cell; padding keeps its own position (>= N)
+        slot[q] = i < N ? (code | (atomicAdd(&s_hist[code], 1) << 12)) : -1;
+    }
+    __syncthreads();
+    {   // exclusive scan of the kCells counts: CPT consecutive cells per thread
+        int c[CPT], sum = 0;
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+            c[e] = s_hist[t * CPT + e];
+            sum += c[e];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        int base = incl - sum;
+        for (int w = 0; w < wave; ++w) base += s_scan[w];
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+            s_hist[t * CPT + e] = base;
+            base += c[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+        slot[q] = slot[q] >= 0 ? s_hist[slot[q] & (kCells - 1)] + (slot[q] >> 12) : q * T + t;
+    // -- permute coordinates and original indices through LDS, one component at a time; wave w then
+    //    owns the sorted positions [w*P*64, (w+1)*P*64), lane-fastest inside each of its P rows
+#pragma unroll
+    for (int comp = 0; comp < 4; ++comp) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const float v = comp == 0 ? px[q] : comp == 1 ? py[q] : comp == 2 ? pz[q] : __int_as_float(q * T + t);
+            s_stage[slot[q]] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const float v = s_stage[(wave * P + q) * 64 + lane];
+            if (comp == 0) px[q] = v;
+            else if (comp == 1) py[q] = v;
+            else if (comp == 2) pz[q] = v;
+            else oidx[q] = __float_as_int(v);
+        }
+    }
+    // -- the wave's bounding box over its real points
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const bool real = (wave * P + q) * 64 + lane < N;
+        run[q] = real ? 1e10f : -1.0f;
+        if (real) {
+            blo[0] = fminf(blo[0], px[q]); bhi[0] = fmaxf(bhi[0], px[q]);
+            blo[1] = fminf(blo[1], py[q]); bhi[1] = fmaxf(bhi[1], py[q]);
+            blo[2] = fminf(blo[2], pz[q]); bhi[2] = fmaxf(bhi[2], pz[q]);
+        } else {
+            oidx[q] = kPad;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        blo[a] = wave_minf(blo[a]);
+        bhi[a] = wave_max(bhi[a]);
+    }
+
+    int far = (int)start[b];
+    far = far < 0 ? 0 : (far >= N ? N - 1 : far);
+    float wmax = 1e10f;   // cached: maximum of run[] over the wave, and the lowest original index attaining it
+    int wcand = kPad;
+    for (int s = 0; s < S; ++s) {
+        if (t == 0) o[s] = (int64_t)far;
+        far = __builtin_amdgcn_readfirstlane(far);
+        const float cx = p[far * 3 + 0];
+        const float cy = p[far * 3 + 1];
+        const float cz = p[far * 3 + 2];
+        // distance from the centroid to the wave's box, rounded like a point distance
+        const float gx = fmaxf(0.0f, fmaxf(__fsub_rn(blo[0], cx), __fsub_rn(cx, bhi[0])));
+        const float gy = fmaxf(0.0f, fmaxf(__fsub_rn(blo[1], cy), __fsub_rn(cy, bhi[1])));
+        const float gz = fmaxf(0.0f, fmaxf(__fsub_rn(blo[2], cz), __fsub_rn(cz, bhi[2])));
+        const float dbox = __fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz));
+        const int active = __builtin_amdgcn_readfirstlane((s == 0 || dbox < wmax) ? 1 : 0);
+        if (active) {
+            float best = -2.0f;
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+#pragma unroll
+            for (int q = 0; q + 1 < P; q += 2) {
+                const f2 dx = f2{px[q], px[q + 1]} - cx2;
+                const f2 dy = f2{py[q], py[q + 1]} - cy2;
+                const f2 dz = f2{pz[q], pz[q + 1]} - cz2;
+                const f2 d = (dx * dx + dy * dy) + dz * dz;
+                run[q] = __builtin_fminf(d.x, run[q]);
+                run[q + 1] = __builtin_fminf(d.y, run[q + 1]);
+                best = __builtin_fmaxf(best, __builtin_fmaxf(run[q], run[q + 1]));
+            }
+            static_assert(P % 2 == 0, "pairs");
+            wmax = wave_max(best);
+            int besti = kPad;
+#pragma unroll
+            for (int q = 0; q < P; ++q) besti = min(besti, run[q] == wmax ? oidx[q] : kPad);
+            wcand = wave_min(besti);
+        }
+        const int buf = s & 1;
+        if (lane == 0) {
+            s_val[buf][wave] = wmax;
+            s_idx[buf][wave] = wcand;
+        }
+        __syncthreads();
+        const float v = s_val[buf][lane % NW];
+        const int vi = s_idx[buf][lane % NW];
+        const float m = row16_max(v);
+        far = row16_min(v == m ? vi : kPad);
+    }
+}
+
 // Larger clouds: running distances live in LDS (40960 floats = 160 KiB), coordinates are re-read
 // from L2 every iteration.  Slower per iteration; exists so that N up to 40960 is served.
 constexpr int kLdsThreads = 1024;
@@ -166,6 +377,20 @@ void launch_regs(const float *xyz, int B, int N, int S, const int64_t *start, in
     hipLaunchKernelGGL((fps_regs_kernel<T, P>), dim3(B), dim3(T), 0, st, xyz, N, S, start, out);
 }
 
+// PCB_FPS_SORTED=0 selects the unsorted kernel for clouds above 2048 points (A/B timing)
+template <int T, int P>
+void launch_sorted(const float *xyz, int B, int N, int S, const int64_t *start, int64_t *out, hipStream_t st)
+{
+    static const bool sorted = [] {
+        const char *e = getenv("PCB_FPS_SORTED");
+        return !(e && e[0] == '0');
+    }();
+    if (sorted)
+        hipLaunchKernelGGL((fps_sorted_kernel<T, P>), dim3(B), dim3(T), 0, st, xyz, N, S, start, out);
+    else
+        launch_regs<T, P>(xyz, B, N, S, start, out, st);
+}
+
 }  // namespace
 
 extern "C" int pcb_fps(const float *xyz, int B, int N, int S, const int64_t *start_idx,
@@ -180,9 +405,9 @@ extern "C" int pcb_fps(const float *xyz, int B, int N, int S, const int64_t *sta
     else if (N <= 512) launch_regs<128, 4>(xyz, B, N, S, start_idx, out_idx, st);
     else if (N <= 1024) launch_regs<256, 4>(xyz, B, N, S, start_idx, out_idx, st);
     else if (N <= 2048) launch_regs<256, 8>(xyz, B, N, S, start_idx, out_idx, st);
-    else if (N <= 4096) launch_regs<512, 8>(xyz, B, N, S, start_idx, out_idx, st);
-    else if (N <= 8192) launch_regs<1024, 8>(xyz, B, N, S, start_idx, out_idx, st);
-    else if (N <= 16384) launch_regs<1024, 16>(xyz, B, N, S, start_idx, out_idx, st);
+    else if (N <= 4096) launch_sorted<512, 8>(xyz, B, N, S, start_idx, out_idx, st);
+    else if (N <= 8192) launch_sorted<1024, 8>(xyz, B, N, S, start_idx, out_idx, st);
+    else if (N <= 16384) launch_sorted<1024, 16>(xyz, B, N, S, start_idx, out_idx, st);
     else if (N <= kLdsMaxN) {
         const size_t lds = sizeof(float) * (size_t)(N + 64);
         if (hipFuncSetAttribute((const void *)fps_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

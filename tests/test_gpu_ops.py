@@ -153,6 +153,41 @@ def test_fps_duplicates_pick_first_index(ops):
     assert np.array_equal(got, orc.farthest_point_sample(xyz.numpy(), 128, start.numpy()))
 
 
+@pytest.mark.parametrize("kind,N,S", [("dup", 6000, 300), ("dup", 16384, 200), ("flat", 9000, 256),
+                                       ("same", 5000, 40), ("grid", 16384, 400), ("line", 8193, 200),
+                                       ("ball", 4097, 128), ("ball", 16383, 512), ("clusters", 12345, 300)])
+def test_fps_sorted_kernel_tie_and_degenerate_clouds(ops, kind, N, S):
+    """The spatially sorted FPS kernel (N > 4096: Morton-sorted cloud, per-wave bounding-box pruning,
+    ties broken on ORIGINAL indices) against the oracle on clouds built to stress it: repeated points,
+    a plane (zero extent along z), one repeated point, an exact grid full of equal distances, a
+    line, sizes that leave ragged last waves, tight clusters (most waves pruned)."""
+    gen = torch.Generator().manual_seed(N + S)
+    B = 2
+    if kind == "dup":
+        base = unit_ball(gen, B, N // 3)
+        xyz = torch.cat([base, base, base[:, :N - 2 * (N // 3)]], dim=1)
+    elif kind == "flat":
+        xyz = unit_ball(gen, B, N)
+        xyz[..., 2] = 0.25
+    elif kind == "same":
+        xyz = torch.full((B, N, 3), 0.5)
+    elif kind == "grid":
+        xyz = torch.randint(-8, 8, (B, N, 3), generator=gen).float() / 8.0
+    elif kind == "line":
+        xyz = torch.zeros(B, N, 3)
+        xyz[..., 0] = torch.rand(B, N, generator=gen)
+    elif kind == "clusters":
+        centres = unit_ball(gen, B, 8)
+        pick = torch.randint(0, 8, (B, N), generator=gen)
+        xyz = torch.gather(centres, 1, pick.unsqueeze(-1).expand(-1, -1, 3)) + 0.01 * torch.randn(B, N, 3, generator=gen)
+    else:
+        xyz = unit_ball(gen, B, N)
+    xyz = xyz.contiguous()
+    start = torch.randint(0, N, (B,), generator=gen)
+    got = ops.furthest_point_sample(xyz.cuda(), S, start.cuda()).cpu().numpy()
+    assert np.array_equal(got, orc.farthest_point_sample(xyz.numpy(), S, start.numpy()))
+
+
 @pytest.mark.parametrize("B,N,S,r,ns", [(2, 1000, 77, 0.15, 16), (1, 4096, 1024, 0.1, 32),
                                          (2, 16384, 130, 0.05, 64), (1, 333, 333, 2.5, 333),
                                          (2, 70, 9, 0.2, 1)])

@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloud_bridge_amd import ops
 torch.manual_seed(0)
-for B, N, S in ((16, 16384, 1024), (16, 1024, 512), (16, 512, 128), (4, 4096, 1024), (8, 8192, 2048)):
+for B, N, S in ((16, 16384, 1024), (16, 1024, 512), (16, 512, 128), (4, 4096, 1024), (16, 4096, 1024), (16, 3000, 512), (8, 8192, 2048)):
     x = torch.rand(B, N, 3, device="cuda"); st = torch.zeros(B, dtype=torch.long, device="cuda")
     for _ in range(2): ops.furthest_point_sample(x, S, st)
     torch.cuda.synchronize()
