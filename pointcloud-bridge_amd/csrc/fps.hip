@@ -109,21 +109,18 @@ __global__ __launch_bounds__(T) void fps_regs_kernel(const float *__restrict__ x
 // ---- spatially sorted variant ----------------------------------------------------------------
 // Same arithmetic, same results; the scan of all N points per iteration is what bounds the kernel
 // above (VALU), and most of it is provably idle: a new centroid c can lower the running minimum of a
-// point p only if d(p,c) < run[p].  The workgroup first sorts its cloud along a Morton curve (16^3
-// cells, counting sort in LDS) so that each WAVE owns a compact box of T*P/NW consecutive points.
+// point p only if d(p,c) < run[p].  The workgroup first sorts its cloud by a 12-bit cell code (binary
+// splits along the currently longest cell axis; counting sort in LDS) so that each WAVE owns a
+// compact box of T*P/NW consecutive points.
 // Per iteration a wave evaluates the distance from c to its box with the SAME rounded operations
 // as the point distance -- fl() is monotonic, so box distance <= every point's computed distance --
 // and if that is >= the wave's current maximum of run[], no lane can change: the wave skips the
 // update, the arg-max search and both reductions and re-publishes its cached (maximum, index).
 // Ties are broken on the ORIGINAL indices (kept beside the coordinates), so the output is
 // bit-identical to the unsorted kernel; the order inside a cell is irrelevant to the result.
-constexpr int kCellBits = 4;
-constexpr int kCells = 1 << (3 * kCellBits);
+constexpr int kCodeBits = 12;
+constexpr int kCells = 1 << kCodeBits;
 
-__device__ __forceinline__ int spread3(int v)  // 4 bits -> every third bit
-{
-    return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6);
-}
 __device__ __forceinline__ float wave_minf(float v) { return -wave_max(-v); }
 
 template <int T, int P>
@@ -173,28 +170,55 @@ __global__ __launch_bounds__(T) void fps_sorted_kernel(const float *__restrict__
     }
     for (int e = t; e < kCells; e += T) s_hist[e] = 0;
     __syncthreads();
+    // Cells: kCodeBits binary splits, each halving the axis along which the cells are currently
+    // longest (a k-d style order decided from the cloud's extents, the same in every lane), so that
+    // elongated or flat clouds -- bridges -- get near-cubic cells as well; on a ball this is the
+    // plain 4/4/4-bit Morton order.
     float inv[3];
+    int bits[3] = {0, 0, 0}, order = 0;
+    {
+        float cell[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float l = s_box[a][0], h = s_box[3 + a][0];
-        for (int w = 1; w < NW; ++w) {
-            l = fminf(l, s_box[a][w]);
-            h = fmaxf(h, s_box[3 + a][w]);
+        for (int a = 0; a < 3; ++a) {
+            float l = s_box[a][0], h = s_box[3 + a][0];
+            for (int w = 1; w < NW; ++w) {
+                l = fminf(l, s_box[a][w]);
+                h = fmaxf(h, s_box[3 + a][w]);
+            }
+            lo[a] = l;
+            cell[a] = h - l;
         }
-        lo[a] = l;
-        inv[a] = h > l ? (float)(1 << kCellBits) / (h - l) : 0.0f;
+        const float ext[3] = {cell[0], cell[1], cell[2]};
+#pragma unroll
+        for (int step = 0; step < kCodeBits; ++step) {
+            const int a = (cell[0] >= cell[1] && cell[0] >= cell[2]) ? 0 : (cell[1] >= cell[2] ? 1 : 2);
+            order |= a << (2 * step);
+            bits[0] += a == 0; bits[1] += a == 1; bits[2] += a == 2;
+            cell[0] *= a == 0 ? 0.5f : 1.0f;
+            cell[1] *= a == 1 ? 0.5f : 1.0f;
+            cell[2] *= a == 2 ? 0.5f : 1.0f;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) inv[a] = ext[a] > 0.0f ? (float)(1 << bits[a]) / ext[a] : 0.0f;
     }
-    // -- counting sort by Morton cell: rank inside the cell from the histogram atomics
+    // -- counting sort by cell code: rank inside the cell from the histogram atomics
     int slot[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) {
         const int i = q * T + t;
-        const int cx = min((1 << kCellBits) - 1, max(0, (int)((px[q] - lo[0]) * inv[0])));
-        const int cy = min((1 << kCellBits) - 1, max(0, (int)((py[q] - lo[1]) * inv[1])));
-        const int cz = min((1 << kCellBits) - 1, max(0, (int)((pz[q] - lo[2]) * inv[2])));
-        const int code = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
-        // low 12 bits: cell, high bits: rank in the cell; padding keeps its own position (>= N)
-        slot[q] = i < N ? (code | (atomicAdd(&s_hist[code], 1) << 12)) : -1;
+        const int qx = min((1 << bits[0]) - 1, max(0, (int)((px[q] - lo[0]) * inv[0])));
+        const int qy = min((1 << bits[1]) - 1, max(0, (int)((py[q] - lo[1]) * inv[1])));
+        const int qz = min((1 << bits[2]) - 1, max(0, (int)((pz[q] - lo[2]) * inv[2])));
+        int rx = bits[0], ry = bits[1], rz = bits[2], code = 0;
+#pragma unroll
+        for (int step = 0; step < kCodeBits; ++step) {  // most significant split first
+            const int a = (order >> (2 * step)) & 3;
+            rx -= a == 0; ry -= a == 1; rz -= a == 2;
+            const int bit = a == 0 ? (qx >> rx) : a == 1 ? (qy >> ry) : (qz >> rz);
+            code = (code << 1) | (bit & 1);
+        }
+        // low kCodeBits bits: cell, high bits: rank in the cell; padding keeps its own position (>= N)
+        slot[q] = i < N ? (code | (atomicAdd(&s_hist[code], 1) << kCodeBits)) : -1;
     }
     __syncthreads();
     {   // exclusive scan of the kCells counts: CPT consecutive cells per thread
@@ -223,7 +247,7 @@ __global__ __launch_bounds__(T) void fps_sorted_kernel(const float *__restrict__
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < P; ++q)
-        slot[q] = slot[q] >= 0 ? s_hist[slot[q] & (kCells - 1)] + (slot[q] >> 12) : q * T + t;
+        slot[q] = slot[q] >= 0 ? s_hist[slot[q] & (kCells - 1)] + (slot[q] >> kCodeBits) : q * T + t;
     // -- permute coordinates and original indices through LDS, one component at a time; wave w then
     //    owns the sorted positions [w*P*64, (w+1)*P*64), lane-fastest inside each of its P rows
 #pragma unroll
