@@ -332,6 +332,21 @@ int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale
  * per-point products of csrc/gatherlin.hip (replaces torch.matmul on R = B*N rows). */
 int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int N, int K, float *out, void *stream);
 
+/*
+ * Conv without BatchNorm (the second conv of EnhancedFeaturePropagation.attention / .boundary_aware,
+ * models/pointnet2_utils.py:232-236, :279-283, and the classifier conv of the heads, models/model.py:98,
+ * models/pointnet2.py:33): out [R,N] bf16 = a [R,K] . w [N,K]^T + bias [N] (fp32, may be NULL), the bias
+ * added to the fp32 accumulators.  N % 8 == 0, K % 8 == 0.
+ * pcb_prep_linear_bias_bf16 builds its operands in one launch from the fp32 parameters: w [n,k] ->
+ * wp [npad,kp] and (optional) wt [kp,npad] bf16, zero padded; bias [n] (or NULL) -> bp [npad] fp32.
+ * gap = D > 0: the n outputs are laid out like interpolate+concat rows (first D in place, the others
+ * from column pad8(D)), so the result can gate / join such rows without a permutation.
+ */
+int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *bias, long R, int N, int K, void *out,
+                          void *stream);
+int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
+                              void *wp, void *wt, float *bp, void *stream);
+
 /* Tell the library that another kernel occupies about `busy_cus` compute units beside the launches
  * that follow (e.g. the next batch's FPS on a side stream during the backward pass): the persistent
  * input-gradient GEMMs then size their grids for the remaining CUs.  0 = the GPU is ours (default).

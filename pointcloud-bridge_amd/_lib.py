@@ -42,6 +42,8 @@ SIGNATURES = {
     "pcb_bn_finalize": [_p, _i, _l, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p],
     "pcb_set_concurrency_hint": [_i],
     "pcb_gemm_nt_partials": [_i, _l, _i],
+    "pcb_gemm_nt_bias_bf16": [_p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_prep_linear_bias_bf16": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "pcb_gemm_nt_f32out_bf16": [_p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_bf16": [_p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_max_bf16": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],

@@ -186,6 +186,7 @@ struct RedArgs {
     const u16 *y;                              // [R, N] bf16: pre-BatchNorm output of the layer below
     const float *scale, *shift, *mean, *invstd;  // its per-column constants
     int act;
+    const float *bias;  // plain epilogue only (no STATS, no RED): out = A'.W^T + bias[N] (a conv without BatchNorm)
 };
 
 template <int PRO, int STATS, int RED, int OUT32 = 0>
@@ -310,10 +311,11 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + j * 32 + (lane & 31);
+                const float bj = (red_arg.bias && n < N) ? red_arg.bias[n] : 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const long r = m0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                    if (r < R && n < N) o32[r * N + n] = acc[j][i];
+                    if (r < R && n < N) o32[r * N + n] = acc[j][i] + bj;
                 }
             }
             __syncthreads();
@@ -340,10 +342,15 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float sv = 0.0f, sq = 0.0f;
+            float bj = 0.0f;
+            if (!STATS && !RED && red_arg.bias) {
+                const int n = n0 + j * 32 + (lane & 31);
+                bj = n < N ? red_arg.bias[n] : 0.0f;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                const u16 h = f2bf(acc[j][i]);
+                const u16 h = f2bf((!STATS && !RED) ? acc[j][i] + bj : acc[j][i]);
                 stage[rr * NT_OUT_LD + j * 32 + (lane & 31)] = h;
                 if (STATS) {
                     const float v = bf2f(h);  // statistics of the values the next kernels will read
@@ -799,7 +806,7 @@ void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, 
 {
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)nt_grid_x(PRO, R, N), ny);
-    RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     if (red && PRO >= PRO_DY)
         hipLaunchKernelGGL((gemm_nt_kernel<PRO, 0, (PRO >= PRO_DY)>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums, *red);
     else if (sums)
@@ -933,13 +940,64 @@ extern "C" int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int
     const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)nt_grid_x(PRO_PLAIN, R, N), ny);
-    const RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);
     hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0, 1>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out,
                        (float *)nullptr, none);
     pcb_timer_end(st, timed, 2.0 * R * K + 4.0 * R * N, 20, R, N, K);
+    return pcb_check_launch();
+}
+
+// y = x W^T + b for a conv without BatchNorm: the plain GEMM with the bias added to the fp32
+// accumulators before rounding.
+extern "C" int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *bias, long R, int N, int K, void *out,
+                                     void *stream)
+{
+    if (!a || !w || !out || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
+    const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
+    const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
+    const dim3 grid((unsigned)nt_grid_x(PRO_PLAIN, R, N), ny);
+    const RedArgs epi = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, bias};
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
+    hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out,
+                       (float *)nullptr, epi);
+    pcb_timer_end(st, timed, nt_bytes(PRO_PLAIN, R, N, K, 0), PRO_PLAIN, R, N, K);
+    return pcb_check_launch();
+}
+
+// Operands of a bias-only conv in one launch: w [n,k] fp32 -> wp [npad,kp] and wt [kp,npad] bf16 (zero
+// padded), bias [n] -> bp [npad] fp32.  gap = D > 0: the n outputs use the interpolate+concat
+// column layout (first D in place, the rest from column pad8(D)), see real_column(.., -D).
+namespace {
+__global__ __launch_bounds__(256) void prep_linear_bias_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                               int n, int k, int npad, int kp, int gap,
+                                                               u16 *__restrict__ wp, u16 *__restrict__ wt,
+                                                               float *__restrict__ bp)
+{
+    const int total = npad * kp;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int o = e / kp, j = e - o * kp;
+        const int r = real_column(o, n, -gap);   // gap = 0: o < n ? o : -1
+        const u16 h = (r >= 0 && j < k) ? f2bf(w[(long)r * k + j]) : (u16)0;
+        wp[e] = h;
+        if (wt) wt[(long)j * npad + o] = h;
+        if (j == 0) bp[o] = (r >= 0 && bias) ? bias[r] : 0.0f;
+    }
+}
+}  // namespace
+
+extern "C" int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
+                                         void *wp, void *wt, float *bp, void *stream)
+{
+    if (!w || !wp || !bp || n <= 0 || k <= 0 || npad < n || kp < k || gap < 0) return PCB_ERR_INVALID_ARG;
+    const int blocks = (npad * kp + 255) / 256;
+    hipLaunchKernelGGL(prep_linear_bias_kernel, dim3(blocks < 64 ? blocks : 64), dim3(256), 0, (hipStream_t)stream, w, bias,
+                       n, k, npad, kp, gap, (u16 *)wp, (u16 *)wt, bp);
     return pcb_check_launch();
 }
 
@@ -1081,7 +1139,7 @@ extern "C" int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, con
     if (pro == PRO_DY_POOL && (!dout || !argmax || ns <= 0 || ns > 255)) return PCB_ERR_INVALID_ARG;
     if (N > NT_BN) return PCB_ERR_UNSUPPORTED;  // one column tile only (the caller checks N <= 128)
     const Operand A = make_operand(a0, a1, K, scale, shift, p, q, dout, argmax, ns, act);
-    const RedArgs red = {(const u16 *)red_y, red_scale, red_shift, red_mean, red_invstd, red_act};
+    const RedArgs red = {(const u16 *)red_y, red_scale, red_shift, red_mean, red_invstd, red_act, nullptr};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);

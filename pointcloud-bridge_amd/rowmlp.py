@@ -589,10 +589,22 @@ def conv_bn_act(conv, bn, x, act=ACT_RELU, pool=0, perm=0, stat_repeat=1):
         training, momentum, bn.eps, act, pool, perm)
 
 
+_gap_rows = {}
+
+
+def _gap_row_index(n, d, device):
+    """Row numbers of the n real outputs inside the interpolate+concat column layout (cached)."""
+    key = (n, d, device)
+    if key not in _gap_rows:
+        dp = pad8(d)
+        _gap_rows[key] = torch.cat([torch.arange(d, device=device), dp + torch.arange(n - d, device=device)])
+    return _gap_rows[key]
+
+
 class _LinearBias(torch.autograd.Function):
-    """y = x W^T + b on bf16 rows (no BatchNorm).  Backward: weight gradient with the split-row
-    MFMA kernel (fp32, no atomics), bias gradient as a column sum (pcb_colstats_bf16) instead of
-    ATen's strided bf16 reduction."""
+    """y = x W^T + b on bf16 rows (no BatchNorm): operands prepared by one kernel, the product with
+    the bias added in the GEMM epilogue.  Backward: input gradient with the same GEMM on W^T, weight
+    gradient with the split-row MFMA kernel (fp32, no atomics), bias gradient as a column sum."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, out_gap):
@@ -600,52 +612,53 @@ class _LinearBias(torch.autograd.Function):
         in place, the rest from column pad8(D); untouched columns are exactly zero) and is returned
         with all its padded columns; out_gap = 0: plain [R, n] output."""
         w = weight.reshape(weight.shape[0], -1)
+        if not (w.is_contiguous() and w.dtype == torch.float32):
+            raise TypeError("bf16 layers expect contiguous fp32 master weights")
         n, k = w.shape
-        kp = x.shape[1]
-        if out_gap:
-            d, dp = out_gap, pad8(out_gap)
-            npad = pad8(dp + n - d)
-            rows = torch.cat([torch.arange(d, device=x.device), dp + torch.arange(n - d, device=x.device)])
-        else:
-            npad = pad8(n)
-            rows = None
-        wp = torch.zeros(npad, kp, dtype=torch.bfloat16, device=x.device)
-        bp = torch.zeros(npad, dtype=torch.bfloat16, device=x.device)
-        if rows is None:
-            wp[:n, :k] = w
-            if bias is not None:
-                bp[:n] = bias
-        else:
-            wp[rows, :k] = w.to(torch.bfloat16)
-            if bias is not None:
-                bp[rows] = bias.to(torch.bfloat16)
-        y = torch.addmm(bp, x, wp.t())
-        ctx.save_for_backward(x, wp, rows)
-        ctx.cfg = (weight.shape, n, k, bias is not None)
+        R, kp = x.shape
+        dev = x.device
+        npad = pad8(pad8(out_gap) + n - out_gap) if out_gap else pad8(n)
+        need_dx = ctx.needs_input_grad[0]
+        wp = torch.empty(npad, kp, dtype=torch.bfloat16, device=dev)
+        wt = torch.empty(kp, npad, dtype=torch.bfloat16, device=dev) if need_dx else None
+        bp = torch.empty(npad, dtype=torch.float32, device=dev)
+        y = torch.empty(R, npad, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            _launch("pcb_prep_linear_bias_bf16", npad * kp, w.data_ptr(), 0 if bias is None else bias.data_ptr(), n, k,
+                    npad, kp, int(out_gap), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), bp.data_ptr())
+            _launch("pcb_gemm_nt_bias_bf16", 2 * R * (npad + kp), x.data_ptr(), wp.data_ptr(), bp.data_ptr(), R, npad, kp,
+                    y.data_ptr())
+        ctx.save_for_backward(x, wt)
+        ctx.cfg = (weight.shape, n, k, bias is not None, int(out_gap), npad)
         return y if out_gap else y[:, :n]
 
     @staticmethod
     def backward(ctx, g):
-        x, wp, rows = ctx.saved_tensors
-        wshape, n, k, has_bias = ctx.cfg
-        npad, kp = wp.shape
-        R = x.shape[0]
+        x, wt = ctx.saved_tensors
+        wshape, n, k, has_bias, out_gap, npad = ctx.cfg
+        R, kp = x.shape
         dev = x.device
         gy = g.to(torch.bfloat16)
         gy = gy.contiguous() if gy.shape[1] == npad else F.pad(gy, (0, npad - gy.shape[1]))
-        dx = torch.mm(gy, wp) if ctx.needs_input_grad[0] else None
-        dw = torch.empty(npad, kp, dtype=torch.float32, device=dev)
+        dx = None
+        dw = torch.empty(npad, k, dtype=torch.float32, device=dev)
         lib = _lib.load()
         ws = torch.empty(lib.pcb_gemm_tn_workspace(R, npad, kp), dtype=torch.float32, device=dev)
         sums = torch.zeros(2, npad, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
+            if wt is not None:
+                dx = torch.empty(R, kp, dtype=torch.bfloat16, device=dev)
+                _launch("pcb_gemm_nt_bf16", 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 0, 0, wt.data_ptr(),
+                        R, kp, npad, dx.data_ptr(), 0)
+            # dW straight in the real [npad, k] layout (the padding columns of x dropped)
             _launch("pcb_gemm_tn_bf16", 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
-                    0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr(), 0, 0)
+                    0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr(), k, 0)
             if has_bias:
                 _launch("pcb_colstats_bf16", R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
-        if rows is None:
-            return dx, dw[:n, :k].reshape(wshape), (sums[0, :n].clone() if has_bias else None), None
-        return dx, dw[rows, :k].reshape(wshape), (sums[0, rows] if has_bias else None), None
+        if not out_gap:
+            return dx, dw[:n].reshape(wshape), (sums[0, :n].clone() if has_bias else None), None
+        rows = _gap_row_index(n, out_gap, dev)
+        return dx, dw[rows].reshape(wshape), (sums[0, rows] if has_bias else None), None
 
 
 def conv_rows(conv, x, out_dtype=None, out_gap=0):
