@@ -51,14 +51,32 @@ def confusion_matrix(pred, target, num_classes):
     return torch.bincount(k, minlength=num_classes * num_classes).view(num_classes, num_classes)
 
 
+def per_scene_confusion(pred, target, num_classes):
+    """[B, num_classes, num_classes] counts of every scene of a batch in one bincount -- the per-file
+    matrices inference.py:186-227 fills point by point."""
+    B = target.shape[0]
+    scene = torch.arange(B, device=target.device).view(B, 1) * (num_classes * num_classes)
+    k = scene + target.reshape(B, -1) * num_classes + pred.reshape(B, -1)
+    return torch.bincount(k.reshape(-1), minlength=B * num_classes * num_classes).view(B, num_classes, num_classes)
+
+
 def metrics_from_confusion(cm):
-    """mIoU / OA / per-class IoU as inference.py:814-855 defines them."""
+    """calculate_metrics, inference.py:814-855, on a [C,C] count matrix (rows = true class): every
+    quotient carries the reference's +1e-6, so a class that occurs nowhere has IoU 0 (not NaN) and
+    DOES enter the mean.  Keys: miou, oa, iou, macc, acc, precision, recall, f1."""
     cm = cm.double()
     diag = cm.diag()
-    iou = diag / (cm.sum(1) + cm.sum(0) - diag + 1e-6)
-    present = cm.sum(1) > 0
-    miou = iou[present].mean() if bool(present.any()) else torch.tensor(float("nan"))
-    return {"miou": float(miou), "oa": float(diag.sum() / cm.sum().clamp(min=1)), "iou": iou.tolist()}
+    rows, cols, total = cm.sum(1), cm.sum(0), cm.sum()
+    iou = diag / (rows + cols - diag + 1e-6)
+    acc = diag / (rows + 1e-6)
+    prec_c = diag / (cols + 1e-6)
+    weights = rows / total
+    precision = (prec_c * weights).sum()
+    recall = (acc * weights).sum()          # recall per class == accuracy per class (:832, :836)
+    f1 = 2 * precision * recall / (precision + recall + 1e-6)
+    return {"miou": float(torch.nanmean(iou)), "oa": float(diag.sum() / total), "iou": iou.tolist(),
+            "macc": float(torch.nanmean(acc)), "acc": acc.tolist(), "precision": float(precision),
+            "recall": float(recall), "f1": float(f1)}
 
 
 class Trainer:

@@ -19,8 +19,33 @@ def test_confusion_and_miou_match_definition():
     assert torch.equal(ref, cm)
     iou = [1 / 3, 2 / 3, 2 / 3, 0.0, 1.0]
     assert all(abs(a - b) < 1e-5 for a, b in zip(m["iou"], iou))
-    assert abs(m["miou"] - (1 / 3 + 2 / 3 + 2 / 3 + 1.0) / 4) < 1e-5   # absent class 3 is skipped (nanmean)
+    # numpy restatement of calculate_metrics, inference.py:814-855 (the module itself needs laspy /
+    # seaborn and cannot be imported): the +1e-6 makes the absent class 3 count as IoU 0 in the mean
+    c = cm.numpy().astype(np.float64)
+    inter, union = np.diag(c), c.sum(1) + c.sum(0) - np.diag(c)
+    acc_c = np.diag(c) / (c.sum(1) + 1e-6)
+    prec_c = np.diag(c) / (c.sum(0) + 1e-6)
+    w = c.sum(1) / c.sum()
+    prec, rec = (prec_c * w).sum(), (acc_c * w).sum()
+    want = {"miou": np.nanmean(inter / (union + 1e-6)), "oa": np.diag(c).sum() / c.sum(), "macc": np.nanmean(acc_c),
+            "precision": prec, "recall": rec, "f1": 2 * prec * rec / (prec + rec + 1e-6)}
+    for k, v in want.items():
+        assert abs(m[k] - v) < 1e-12, k
+    assert abs(m["miou"] - (1 / 3 + 2 / 3 + 2 / 3 + 0 + 1.0) / 5) < 1e-5
     assert abs(m["oa"] - 6 / 8) < 1e-9
+
+
+def test_per_scene_confusion_equals_the_per_point_loops():
+    g = torch.Generator().manual_seed(2)
+    target = torch.randint(0, 5, (3, 200), generator=g)
+    pred = torch.randint(0, 5, (3, 200), generator=g)
+    got = train.per_scene_confusion(pred, target, 5)
+    for i in range(3):                                   # inference.py:226-227
+        ref = torch.zeros(5, 5, dtype=torch.long)
+        for t, p in zip(target[i].view(-1), pred[i].view(-1)):
+            ref[t, p] += 1
+        assert torch.equal(got[i], ref)
+    assert torch.equal(got.sum(0), train.confusion_matrix(pred, target, 5))   # :230-231
 
 
 def test_losses_for_both_logit_layouts():
