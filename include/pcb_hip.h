@@ -472,7 +472,8 @@ int pcb_gate_bwd_bf16(const void *g, const void *x, const void *a, void *dx, voi
  *         input gradient dx will be wanted);   stz fp32 [10 * sum C] (per-layer constants);
  *   parts fp32, >= 2 * C * pcb_gemm_nt_partials(pro,R,C) for every layer (statistics slabs).
  * Backward only: g = dz bf16 [R,C_last] (pool 0) or dout fp32 [R/ns,C_last]; workspace fp32, >= the
- * largest pcb_gemm_tn_workspace(R,C,Kp_l); dzbuf bf16 [2][R][max width] (L > 1); dx bf16 [R,Kp] or NULL.
+ * SUM of pcb_gemm_tn_workspace(R,C_l,Kp_l) over the layers that have a dW (each keeps its slabs until
+ * one launch at the end of the pass sums them all); dzbuf bf16 [2][R][max width] (L > 1); dx bf16 [R,Kp] or NULL.
  */
 #define PCB_STACK_MAX_LAYERS 16
 long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, int need_wt0);

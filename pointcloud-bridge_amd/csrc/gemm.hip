@@ -725,6 +725,45 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restr
     }
 }
 
+// The same sum for up to kMaxPending weight gradients in ONE launch (blockIdx.y = entry): a stack's
+// backward pass parks the reductions of its layers (nothing in that pass reads dW) and runs them
+// together at its end instead of one 5-10 us launch behind every weight-gradient GEMM.
+constexpr int kMaxPending = 16;
+struct PendingReduce {
+    const float *part;
+    float *dW;
+    long elems;
+    int splits, N, k, perm;
+};
+struct ReduceBatch {
+    PendingReduce e[kMaxPending];
+};
+__global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch batch)
+{
+    __shared__ float red[16][64];
+    const PendingReduce r = batch.e[blockIdx.y];
+    const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    for (long e0 = (long)blockIdx.x * 64; e0 < r.elems; e0 += (long)gridDim.x * 64) {
+        const long e = e0 + ex;
+        float a = 0.0f;
+        if (e < r.elems)
+            for (int s = sy; s < r.splits; s += 16) a += r.part[(long)s * r.elems + e];
+        red[sy][ex] = a;
+        __syncthreads();
+        if (sy == 0 && e < r.elems) {
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += red[i][ex];
+            const long m = e / r.N;
+            const int c = real_column((int)(e - m * r.N), r.k, r.perm);
+            if (c >= 0) r.dW[m * r.k + c] = t;
+        }
+        __syncthreads();
+    }
+}
+thread_local ReduceBatch g_pending;
+thread_local int g_npending = -1;  // < 0: every reduction runs right behind its GEMM (the default)
+
 // p, q of the fused BatchNorm backward of one layer from sums = [nparts][2][C] partial slabs of
 // (sum du, sum du*xhat); the parameter gradients the totals amount to go to dgamma, dbeta, dbias
 // ([C] each, optional): dbeta = s1, dgamma = s2, dbias = 0 under batch statistics (the mean
@@ -844,6 +883,10 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
     else
         hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, tm, tn);
     const long elems = (long)M * N;
+    if (g_npending >= 0 && g_npending < kMaxPending && out_cols > 0) {
+        g_pending.e[g_npending++] = {part, dW, elems, (int)splits, N, out_cols, out_perm};
+        return;
+    }
     long blocks = (elems + 63) / 64;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, part, (int)splits, elems, dW, N,
@@ -1038,6 +1081,23 @@ extern "C" int pcb_gemm_nt_partials(int pro, long R, int N)
 {
     if (R <= 0 || N <= 0 || pro < 0 || pro > 3) return 0;
     return (int)nt_grid_x(pro, R, N);
+}
+
+// Deferred slab reductions (see reduce_slabs_multi_kernel): between begin and flush every
+// pcb_gemm_tn_bf16 on this thread needs its OWN workspace region.
+void pcb_defer_reduces_begin() { g_npending = 0; }
+
+int pcb_defer_reduces_flush(hipStream_t st)
+{
+    const int n = g_npending;
+    g_npending = -1;
+    if (n <= 0) return PCB_OK;
+    long most = 0;
+    for (int i = 0; i < n; ++i) most = g_pending.e[i].elems > most ? g_pending.e[i].elems : most;
+    long blocks = (most + 63) / 64;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(1024), 0, st, g_pending);
+    return pcb_check_launch();
 }
 
 extern "C" long pcb_gemm_tn_workspace(long R, int M, int N)

@@ -86,6 +86,10 @@ __device__ __forceinline__ int clamp_index(int64_t j, int n)
 void pcb_timer_begin(hipStream_t st, hipEvent_t *stop);
 void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes, int pro, long R, int N, int K);
 
+// weight-gradient slab reductions of a whole stack in one launch (gemm.hip)
+void pcb_defer_reduces_begin();
+int pcb_defer_reduces_flush(hipStream_t st);
+
 static inline int pcb_check_launch()
 {
     return hipGetLastError() == hipSuccess ? PCB_OK : PCB_ERR_LAUNCH;

@@ -388,6 +388,17 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
     const float *dout = pool ? (const float *)g : nullptr;  // pooled upstream gradient (fp32)
     bool have_parts = false;  // sums of layer l already accumulated by the dgrad GEMM of layer l+1
     int have_nparts = 0;
+    // every layer's weight-gradient GEMM has its own slab region, so that the slab sums of the whole
+    // stack can run as one launch at the end (nothing in this pass reads dW)
+    long ws_off[PCB_STACK_MAX_LAYERS];
+    {
+        long off = 0;
+        for (int l = 0; l < L; ++l) {
+            ws_off[l] = off;
+            if (ly[l].dW && !(gathered && l == 0)) off += pcb_gemm_tn_workspace(R, ly[l].C, ly[l].kp);
+        }
+    }
+    if (!side) pcb_defer_reduces_begin();
     auto layers = [&]() -> int {
         for (int l = L - 1; l >= 0; --l) {
             const Layer &a = ly[l];
@@ -432,11 +443,11 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
                 if (l) {
                     const Layer &b = ly[l - 1];
                     PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 1, b.y,
-                                             row(stz, b, 2), row(stz, b, 3), act, R, a.C, a.kp, workspace, a.dW, a.k, 0,
-                                             tn_stream));
+                                             row(stz, b, 2), row(stz, b, 3), act, R, a.C, a.kp, workspace + ws_off[l], a.dW,
+                                             a.k, 0, tn_stream));
                 } else {
                     PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 0, x, nullptr,
-                                             nullptr, 0, R, a.C, a.kp, workspace, a.dW, a.k, perm, tn_stream));
+                                             nullptr, 0, R, a.C, a.kp, workspace + ws_off[l], a.dW, a.k, perm, tn_stream));
                 }
                 if (tn_stream != stream) {
                     tn_done = side->event();
@@ -465,7 +476,8 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
         return PCB_OK;
     };
     const int status = layers();
+    const int flushed = pcb_defer_reduces_flush(main_st);  // the parked slab sums, one launch (also on an error path)
     // join: everything the side stream did is ordered before whatever the caller enqueues next
     if (tn_done && hipStreamWaitEvent(main_st, tn_done, 0) != hipSuccess) return PCB_ERR_LAUNCH;
-    return status;
+    return status != PCB_OK ? status : flushed;
 }

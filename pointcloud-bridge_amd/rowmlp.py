@@ -299,7 +299,7 @@ class _FusedStack(torch.autograd.Function):
             dbeta = grads[base + 3] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
             outs.append((dw, dgamma, dbeta, dbias))
             if dw is not None:
-                ws_elems = max(ws_elems, lib.pcb_gemm_tn_workspace(R, C, kp))
+                ws_elems += lib.pcb_gemm_tn_workspace(R, C, kp)  # one slab region per layer
             kp = C
         layers = [(w, None, None, None, None, None, flags[l][2]) for l, w in enumerate(weights)]
         desc = _stack_desc(layers, widths, ybuf, R, outs)
@@ -439,7 +439,7 @@ class _GatheredStack(torch.autograd.Function):
             dw = None
             if l and ctx.needs_input_grad[H + base]:
                 dw = grads[base + 0] = torch.empty_like(weights[l])
-                ws_elems = max(ws_elems, lib.pcb_gemm_tn_workspace(R, C, widths[l - 1]))
+                ws_elems += lib.pcb_gemm_tn_workspace(R, C, widths[l - 1])  # one slab region per layer
             dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev) if has_bias else None
             dgamma = grads[base + 2] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
             dbeta = grads[base + 3] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
