@@ -149,6 +149,20 @@ int pcb_interpolate_bwd(const float *grad_out, const float *w, const int64_t *id
 int pcb_knn(const float *x, int B, int N, int D, int k, float *norms, int64_t *out_idx, void *stream);
 
 /*
+ * kNN on 3-D coordinates (the D = 3 case of pcb_knn: DGCNN's first graph, models/DGCNN.py:134, and
+ * torch.cdist + topk of BridgeStructureEncoding, models/attention_modules.py:584-586) through a
+ * uniform grid: the cloud is sorted by cell and every query looks at the cells around it in growing
+ * cubes until its k-th best distance is provably final.  SAME output as pcb_knn(x = xyz, D = 3):
+ * same pd arithmetic, ties by lower index, nearest first.  Scenes whose points crowd into few
+ * cells and clouds outside 1024 <= N <= 16384 are computed with all pairs (the pcb_knn kernel).
+ *   workspace: pcb_knn_xyz_workspace(B, N) bytes of caller-owned scratch (NULL: all pairs)
+ *   norms [B,N] fp32: scratch as in pcb_knn.
+ */
+long pcb_knn_xyz_workspace(int B, int N);
+int pcb_knn_xyz(const float *xyz, int B, int N, int k, float *norms, void *workspace, int64_t *out_idx,
+                void *stream);
+
+/*
  * Local-structure descriptor of the k-neighbourhood of every point.  Replaces the neighbour gather
  * and get_structure_features of BridgeStructureEncoding, models/attention_modules.py:595-603 and
  * :620-687 (rel = x_j - x_i; ascending eigenvalues e of rel^T rel/(k-1) by batched eigh; the

@@ -26,6 +26,8 @@ SIGNATURES = {
     "pcb_interpolate": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "pcb_interpolate_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "pcb_knn": [_p, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_knn_xyz_workspace": [_i, _i],
+    "pcb_knn_xyz": [_p, _i, _i, _i, _p, _p, _p, _p],
     "pcb_structure_features": [_p, _p, _i, _i, _i, _p, _p, _p],
     "pcb_rows_linear_f32": [_p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_rows_linear_dgrad_f32": [_p, _p, _l, _i, _i, _p, _p],
@@ -98,7 +100,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the build lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "pcb_status_string"
-                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems")
+                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems", "pcb_knn_xyz_workspace")
                           else ctypes.c_int)
         _lib = lib
     return _lib

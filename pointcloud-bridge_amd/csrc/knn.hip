@@ -94,8 +94,11 @@ __global__ __launch_bounds__(kThreads) void knn_norms_kernel(const float *__rest
 template <int DP, int K>
 __global__ __launch_bounds__(kThreads, 2) void knn_mfma_kernel(const float *__restrict__ x,
                                                              const float *__restrict__ norms, int N, int D,
-                                                             int k, int64_t *__restrict__ out)
+                                                             int k, int64_t *__restrict__ out,
+                                                             const int *__restrict__ only_if, int only_if_stride)
 {
+    // optional per-scene switch (csrc/knngrid.hip serves the other scenes): uniform per workgroup
+    if (only_if && only_if[(size_t)blockIdx.y * only_if_stride] == 0) return;
     constexpr int S = DP / 2;         // MFMA steps per tile (two channels each)
     constexpr int LD = DP + 4;        // LDS row stride in floats: rows 16 B apart in bank space
     constexpr int kTC = DP <= 32 ? 128 : (DP <= 64 ? 64 : 32);  // candidates per LDS stage (<= 17.4 KB)
@@ -251,18 +254,19 @@ __global__ __launch_bounds__(kThreads, 2) void knn_mfma_kernel(const float *__re
 }
 
 template <int DP>
-int launch_knn(const float *x, float *norms, int B, int N, int D, int k, int64_t *out, hipStream_t st)
+int launch_knn(const float *x, float *norms, int B, int N, int D, int k, int64_t *out, hipStream_t st,
+               const int *only_if = nullptr, int stride = 0)
 {
     const long rows = (long)B * N;
     hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, x,
                        rows, D, norms);
     const dim3 grid((N + 127) / 128, B);
     if (k <= 8)
-        hipLaunchKernelGGL((knn_mfma_kernel<DP, 8>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out);
+        hipLaunchKernelGGL((knn_mfma_kernel<DP, 8>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out, only_if, stride);
     else if (k <= 20)
-        hipLaunchKernelGGL((knn_mfma_kernel<DP, 20>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out);
+        hipLaunchKernelGGL((knn_mfma_kernel<DP, 20>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out, only_if, stride);
     else
-        hipLaunchKernelGGL((knn_mfma_kernel<DP, 32>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out);
+        hipLaunchKernelGGL((knn_mfma_kernel<DP, 32>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out, only_if, stride);
     return pcb_check_launch();
 }
 
@@ -280,4 +284,16 @@ extern "C" int pcb_knn(const float *x, int B, int N, int D, int k, float *norms,
     if (D <= 32) return launch_knn<32>(x, norms, B, N, D, k, out_idx, st);
     if (D <= 64) return launch_knn<64>(x, norms, B, N, D, k, out_idx, st);
     return launch_knn<128>(x, norms, B, N, D, k, out_idx, st);
+}
+
+// pcb_knn with a per-scene switch: scene b is computed only if only_if[b * stride] != 0 (NULL: all).
+int pcb_knn_flagged(const float *x, int B, int N, int D, int k, float *norms, int64_t *out_idx, const int *only_if,
+                    int only_if_stride, hipStream_t st)
+{
+    if (D <= 4) return launch_knn<4>(x, norms, B, N, D, k, out_idx, st, only_if, only_if_stride);
+    if (D <= 8) return launch_knn<8>(x, norms, B, N, D, k, out_idx, st, only_if, only_if_stride);
+    if (D <= 16) return launch_knn<16>(x, norms, B, N, D, k, out_idx, st, only_if, only_if_stride);
+    if (D <= 32) return launch_knn<32>(x, norms, B, N, D, k, out_idx, st, only_if, only_if_stride);
+    if (D <= 64) return launch_knn<64>(x, norms, B, N, D, k, out_idx, st, only_if, only_if_stride);
+    return launch_knn<128>(x, norms, B, N, D, k, out_idx, st, only_if, only_if_stride);
 }

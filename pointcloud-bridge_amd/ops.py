@@ -229,8 +229,21 @@ def knn(x_bnd, k):
     out = torch.empty(B, N, k, dtype=torch.int64, device=x.device)
     norms = torch.empty(B, N, dtype=torch.float32, device=x.device)  # |x|^2 scratch of the kernel
     with torch.cuda.device(x.device):
-        _launch("pcb_knn", B * N * N, x.data_ptr(), B, N, D, k, norms.data_ptr(), out.data_ptr())
+        if D == 3 and _GRID_KNN:
+            # coordinates: the grid search of csrc/knngrid.hip (same output as the all-pairs kernel)
+            ws = torch.empty(_lib.load().pcb_knn_xyz_workspace(B, N), dtype=torch.uint8, device=x.device)
+            _launch("pcb_knn_xyz", B * N * k, x.data_ptr(), B, N, k, norms.data_ptr(), ws.data_ptr(), out.data_ptr())
+        else:
+            _launch("pcb_knn", B * N * N, x.data_ptr(), B, N, D, k, norms.data_ptr(), out.data_ptr())
     return out
+
+
+_GRID_KNN = os.environ.get("PCB_GRID_KNN", "1") != "0"  # 0: all-pairs kernel for coordinates too (A/B timing)
+
+
+def set_grid_knn(flag):
+    global _GRID_KNN
+    _GRID_KNN = bool(flag)
 
 
 def structure_features(xyz, idx, with_offsets=True):

@@ -343,3 +343,44 @@ def test_full_size_properties_cfg3_knn(ops):
     d = ((x[bi, idx] - x.unsqueeze(2)) ** 2).sum(-1)
     assert bool((d[:, :, 1:] >= d[:, :, :-1] - 1e-6).all())                        # sorted by distance
     assert np.array_equal(idx[0, :512].cpu().numpy(), orc.knn(x[:1].cpu().numpy(), k)[0, :512])
+
+
+@pytest.mark.parametrize("kind,B,N,k", [("ball", 2, 16384, 32), ("ball", 3, 5000, 16), ("ball", 2, 1024, 20),
+                                         ("flat", 2, 9000, 32), ("line", 2, 4096, 8), ("dup", 2, 6000, 20),
+                                         ("grid", 2, 8000, 32), ("clusters", 2, 12345, 16), ("outlier", 2, 7000, 20),
+                                         ("same", 1, 2048, 5), ("aniso", 2, 16000, 32), ("ball", 1, 16384, 1)])
+def test_grid_knn_equals_all_pairs_kernel(ops, kind, B, N, k):
+    """pcb_knn_xyz (grid search) must return exactly what pcb_knn returns on the coordinates -- same pd
+    arithmetic, same tie rule, same order -- on clouds built to stress it: a plane, a line, repeated
+    points, an exact lattice full of ties, tight clusters and a far outlier (crowded cells: the
+    all-pairs fallback), one repeated point, anisotropic extents."""
+    gen = torch.Generator().manual_seed(N + k)
+    if kind == "flat":
+        xyz = unit_ball(gen, B, N); xyz[..., 2] = -0.3
+    elif kind == "line":
+        xyz = torch.zeros(B, N, 3); xyz[..., 1] = torch.rand(B, N, generator=gen)
+    elif kind == "dup":
+        base = unit_ball(gen, B, N // 2); xyz = torch.cat([base, base], dim=1)
+    elif kind == "grid":
+        xyz = torch.randint(-16, 16, (B, N, 3), generator=gen).float() / 16.0
+    elif kind == "clusters":
+        centres = unit_ball(gen, B, 8)
+        pick = torch.randint(0, 8, (B, N), generator=gen)
+        xyz = torch.gather(centres, 1, pick.unsqueeze(-1).expand(-1, -1, 3)) + 0.01 * torch.randn(B, N, 3, generator=gen)
+    elif kind == "outlier":
+        xyz = unit_ball(gen, B, N); xyz[:, 0] = torch.tensor([300.0, -200.0, 50.0])
+    elif kind == "same":
+        xyz = torch.full((B, N, 3), 0.25)
+    elif kind == "aniso":
+        xyz = unit_ball(gen, B, N) * torch.tensor([1.0, 0.1, 0.03])
+    else:
+        xyz = unit_ball(gen, B, N)
+    xyz = xyz.contiguous().cuda()
+    try:
+        ops.set_grid_knn(False)
+        want = ops.knn(xyz, k)
+        ops.set_grid_knn(True)
+        got = ops.knn(xyz, k)
+    finally:
+        ops.set_grid_knn(True)
+    assert torch.equal(got, want)
