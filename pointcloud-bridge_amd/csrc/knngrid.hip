@@ -330,6 +330,9 @@ extern "C" int pcb_knn_xyz(const float *xyz, int B, int N, int k, float *norms, 
     if (k <= 16)
         hipLaunchKernelGGL(knn_grid_query_kernel<16>, grid, dim3(kQueryThreads), 0, st, sorted, oidx, cell_start, params, N,
                            k, out_idx);
+    else if (k <= 24)  // DGCNN's k = 20: 48 KB of LDS per workgroup instead of 64, a shorter rescan
+        hipLaunchKernelGGL(knn_grid_query_kernel<24>, grid, dim3(kQueryThreads), 0, st, sorted, oidx, cell_start, params, N,
+                           k, out_idx);
     else
         hipLaunchKernelGGL(knn_grid_query_kernel<32>, grid, dim3(kQueryThreads), 0, st, sorted, oidx, cell_start, params, N,
                            k, out_idx);
