@@ -485,6 +485,9 @@ int pcb_gate_bwd_bf16(const void *g, const void *x, const void *a, void *dx, voi
  *   wbuf  bf16, pcb_mlp_stack_wbuf_elems(L,desc,Kp,need_wt0) elements (prepared weights; need_wt0 = the
  *         input gradient dx will be wanted);   stz fp32 [10 * sum C] (per-layer constants);
  *   parts fp32, >= 2 * C * pcb_gemm_nt_partials(pro,R,C) for every layer (statistics slabs).
+ * Forward, need_wt0 bit 1 (value 2): every layer is in eval mode and wbuf / stz still hold what an
+ * earlier call with the same, unchanged parameters and running statistics left there -- operand
+ * preparation and the per-layer BatchNorm finalize are skipped (inference with constant weights).
  * Backward only: g = dz bf16 [R,C_last] (pool 0) or dout fp32 [R/ns,C_last]; workspace fp32, >= the
  * SUM of pcb_gemm_tn_workspace(R,C_l,Kp_l) over the layers that have a dW (each keeps its slabs until
  * one launch at the end of the pass sums them all); dzbuf bf16 [2][R][max width] (L > 1); dx bf16 [R,Kp] or NULL.

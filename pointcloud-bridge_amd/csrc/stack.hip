@@ -296,19 +296,26 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
         if (!ga.u || !ga.idx || (long)ga.B * ga.S * ga.ns != R || !parts) return PCB_ERR_INVALID_ARG;
         Kp = 0;
     }
+    // need_wt0 bit 1: wbuf and stz still hold the operands and BatchNorm constants an earlier
+    // eval-mode call prepared from the same, unchanged parameters -- no preparation, no finalize
+    const bool ready = (need_wt0 & 2) != 0;
+    need_wt0 &= 1;
     PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, ly));
     if (!fdesc || (!x && !gathered) || (!wbuf && !(gathered && L == 1)) || !stz || !out || R <= 0 || pool < 0 ||
         (pool && (!argmax || R % pool)))
         return PCB_ERR_INVALID_ARG;
+    if (ready)
+        for (int l = 0; l < L; ++l)
+            if (ly[l].training) return PCB_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     unsigned short *wb = (unsigned short *)wbuf;
 
     long stz_floats = 0;
     for (int l = 0; l < L; ++l) stz_floats += 10L * ly[l].C;
-    bool cleared = false;  // stz is cleared by the first weight-preparation launch (or a memset if there is none)
+    bool cleared = ready;  // stz is cleared by the first weight-preparation launch (or a memset if there is none)
 
     // bf16 operands of all layers (chunks of 8 layers per launch)
-    for (int l0 = gathered ? 1 : 0; l0 < L; l0 += 8) {
+    for (int l0 = gathered ? 1 : 0; l0 < L && !ready; l0 += 8) {
         const int n = L - l0 < 8 ? L - l0 : 8;
         long long pd[8 * 8];
         for (int i = 0; i < n; ++i) {
@@ -345,9 +352,11 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
                                      act, wb + a.wp_off, R, a.C, a.kp, a.y, stats ? parts : nullptr, stream));
             nparts = pcb_gemm_nt_partials(l ? 1 : 0, R, a.C);
         }
-        PCB_TRY(pcb_bn_finalize(stats ? parts : nullptr, nparts, R, R * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma, a.beta, a.bias, a.rmean, a.rvar,
-                                (float)fdesc[2 * l], (float)fdesc[2 * l + 1], a.training, row(stz, a, 2),
-                                row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), a.nbt, stream));
+        if (!ready)
+            PCB_TRY(pcb_bn_finalize(stats ? parts : nullptr, nparts, R, R * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma,
+                                    a.beta, a.bias, a.rmean, a.rvar, (float)fdesc[2 * l], (float)fdesc[2 * l + 1],
+                                    a.training, row(stz, a, 2), row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), a.nbt,
+                                    stream));
         cur = a.y;
     }
     const Layer &last = ly[L - 1];

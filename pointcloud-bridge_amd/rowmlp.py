@@ -16,6 +16,7 @@ Both modes read the parameters of the caller's stock nn.Conv*/nn.BatchNorm* modu
 running statistics exactly as nn.BatchNorm does, so state_dicts stay interchangeable.
 """
 import ctypes
+import weakref
 
 import torch
 import torch.nn as nn
@@ -232,6 +233,30 @@ def _rows_bf16(x, kp):
     return F.pad(x, (0, kp - x.shape[1]))
 
 
+# Inference with constant weights: the bf16 operands and the eval-mode BatchNorm constants of a stack
+# depend on parameters and running statistics only, so a no-grad eval-mode call keeps them (keyed by the
+# first weight tensor, validated by every tensor's version counter) and the next call skips their
+# preparation (23 + 34 launches of a PN2-MSG forward pass).
+_eval_operands = {}
+
+
+def _eval_lookup(layers, first, extra):
+    """(key, versions, (wbuf, stz) or None) for a no-grad call whose layers are all in eval mode."""
+    tensors = [t for lay in layers for t in lay[:6] if t is not None]
+    versions = tuple(t._version for t in tensors) + tuple(t.data_ptr() for t in tensors)
+    key = (id(first),) + extra
+    hit = _eval_operands.get(key)
+    if hit is not None and hit[0]() is first and hit[1] == versions:
+        return key, versions, hit[2]
+    return key, versions, None
+
+
+def _eval_store(key, first, versions, bufs):
+    if len(_eval_operands) > 4096:
+        _eval_operands.clear()
+    _eval_operands[key] = (weakref.ref(first), versions, bufs)
+
+
 class _FusedStack(torch.autograd.Function):
     """A stack of L layers act(BN(. W^T)) on bf16 rows with everything between the GEMMs fused
     (csrc/gemm.hip): layer l's BatchNorm+activation is applied while layer l+1 loads its operand,
@@ -258,7 +283,15 @@ class _FusedStack(torch.autograd.Function):
         stz = torch.empty(10 * sum(widths), dtype=torch.float32, device=dev)
         parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
         desc = _stack_desc(layers, widths, ybuf, R)
-        wbuf = torch.empty(lib.pcb_mlp_stack_wbuf_elems(L, desc, Kp, int(need_dx)), dtype=torch.bfloat16, device=dev)
+        ready = 0
+        cache_key = None
+        if not torch.is_grad_enabled() and not any(t[6] for t in layers):
+            cache_key, versions, hit = _eval_lookup(layers, layers[0][0], ("stack", Kp, perm, L))
+            if hit is not None:
+                wbuf, stz = hit
+                ready = 2
+        if not ready:
+            wbuf = torch.empty(lib.pcb_mlp_stack_wbuf_elems(L, desc, Kp, int(need_dx)), dtype=torch.bfloat16, device=dev)
         fdesc = (ctypes.c_double * (2 * L))(*[float(v) for t in layers for v in (t[7], t[8])])
         C = widths[-1]
         if pool:
@@ -268,9 +301,11 @@ class _FusedStack(torch.autograd.Function):
             out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
             arg = None
         with torch.cuda.device(dev):
-            _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, x.data_ptr(), R, Kp, perm, act, pool, int(need_dx),
+            _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, x.data_ptr(), R, Kp, perm, act, pool, int(need_dx) | ready,
                     int(stat_repeat), 0, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
                     0 if arg is None else arg.data_ptr())
+        if cache_key is not None and not ready:
+            _eval_store(cache_key, layers[0][0], versions, (wbuf, stz))
         ctx.save_for_backward(x, arg, ybuf, stz, wbuf, *[t[0] for t in layers])
         ctx.cfg = (act, pool, perm, L, need_dx, [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
         return out
@@ -395,8 +430,17 @@ class _GatheredStack(torch.autograd.Function):
         stz = torch.empty(10 * sum(widths), dtype=torch.float32, device=dev)
         parts = torch.empty(max(_MAX_PARTS, 1024) * 2 * max(widths), dtype=torch.float32, device=dev)
         desc = _stack_desc(layers, widths, ybuf, R)
-        nw = lib.pcb_mlp_stack_wbuf_elems(L, desc, 0, 0)
-        wbuf = torch.empty(max(nw, 1), dtype=torch.bfloat16, device=dev)
+        ready = 0
+        cache_key = None
+        if not torch.is_grad_enabled() and not any(t[6] for t in layers):
+            first = next(t for lay in layers for t in lay[:6] if t is not None)
+            cache_key, versions, hit = _eval_lookup(layers, first, ("gathered", L))
+            if hit is not None:
+                wbuf, stz = hit
+                ready = 2
+        if not ready:
+            nw = lib.pcb_mlp_stack_wbuf_elems(L, desc, 0, 0)
+            wbuf = torch.empty(max(nw, 1), dtype=torch.bfloat16, device=dev)
         fdesc = (ctypes.c_double * (2 * L))(*[float(x) for t in layers for x in (t[7], t[8])])
         gather = (ctypes.c_longlong * 12)(
             u.data_ptr(), 0 if v is None else v.data_ptr(), idx.data_ptr(), B, N, S, ns,
@@ -410,9 +454,11 @@ class _GatheredStack(torch.autograd.Function):
             out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
             arg = None
         with torch.cuda.device(dev):
-            _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, 0, R, 0, 0, act, pool, 0, 1, gather,
+            _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, 0, R, 0, 0, act, pool, ready, 1, gather,
                     wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
                     0 if arg is None else arg.data_ptr())
+        if cache_key is not None and not ready:
+            _eval_store(cache_key, first, versions, (wbuf, stz))
         ctx.save_for_backward(idx, arg, ybuf, stz, wbuf, xyz if wx is not None else None,
                               ctr if wx is not None else None, *[t[0] for t in layers[1:]])
         ctx.cfg = (act, pool, L, ns, B, N, S, widths, v is not None, wx is not None,
@@ -619,15 +665,24 @@ class _LinearBias(torch.autograd.Function):
         dev = x.device
         npad = pad8(pad8(out_gap) + n - out_gap) if out_gap else pad8(n)
         need_dx = ctx.needs_input_grad[0]
-        wp = torch.empty(npad, kp, dtype=torch.bfloat16, device=dev)
-        wt = torch.empty(kp, npad, dtype=torch.bfloat16, device=dev) if need_dx else None
-        bp = torch.empty(npad, dtype=torch.float32, device=dev)
+        cache_key = hit = None
+        if not torch.is_grad_enabled():  # constant weights: keep the prepared operands (see _eval_lookup)
+            cache_key, versions, hit = _eval_lookup([(weight, bias)], weight, ("linear", kp, int(out_gap)))
+        if hit is not None:
+            wp, wt, bp = hit
+        else:
+            wp = torch.empty(npad, kp, dtype=torch.bfloat16, device=dev)
+            wt = torch.empty(kp, npad, dtype=torch.bfloat16, device=dev) if need_dx else None
+            bp = torch.empty(npad, dtype=torch.float32, device=dev)
         y = torch.empty(R, npad, dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
-            _launch("pcb_prep_linear_bias_bf16", npad * kp, w.data_ptr(), 0 if bias is None else bias.data_ptr(), n, k,
-                    npad, kp, int(out_gap), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), bp.data_ptr())
+            if hit is None:
+                _launch("pcb_prep_linear_bias_bf16", npad * kp, w.data_ptr(), 0 if bias is None else bias.data_ptr(), n, k,
+                        npad, kp, int(out_gap), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), bp.data_ptr())
             _launch("pcb_gemm_nt_bias_bf16", 2 * R * (npad + kp), x.data_ptr(), wp.data_ptr(), bp.data_ptr(), R, npad, kp,
                     y.data_ptr())
+        if cache_key is not None and hit is None:
+            _eval_store(cache_key, weight, versions, (wp, wt, bp))
         ctx.save_for_backward(x, wt)
         ctx.cfg = (weight.shape, n, k, bias is not None, int(out_gap), npad)
         return y if out_gap else y[:, :n]

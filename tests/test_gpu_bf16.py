@@ -560,3 +560,39 @@ def test_gate_rows_matches_torch(rm):
     assert torch.allclose(out.float(), ref, rtol=2 ** -7, atol=1e-3)
     assert torch.allclose(x1.grad.float(), x2.grad, rtol=2 ** -7, atol=1e-3)
     assert torch.allclose(a1.grad.float(), a2.grad, rtol=2 ** -7, atol=1e-3)
+
+
+def test_eval_operand_cache_is_transparent_and_invalidated_by_updates():
+    """No-grad eval-mode calls keep the prepared bf16 operands / BatchNorm constants of a stack.  The
+    second call (cache hit) must equal the first bit for bit, and a parameter or running-statistics
+    update must be picked up (version counters), as must a fresh module at the same address."""
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models.containers import PointNet2MSG
+    rowmlp.set_precision("bf16")
+    try:
+        torch.manual_seed(1)
+        g = torch.Generator().manual_seed(3)
+        v = torch.randn(2, 2048, 3, generator=g)
+        xyz = (v / v.norm(dim=-1, keepdim=True) * torch.rand(2, 2048, 1, generator=g) ** (1 / 3)).cuda()
+        colors = torch.rand(2, 2048, 3, generator=g).cuda()
+        model = PointNet2MSG(5).cuda().eval()
+
+        def run():
+            torch.manual_seed(9)  # FPS start indices
+            with torch.no_grad():
+                return model(xyz, colors).float()
+
+        a = run()
+        b = run()
+        assert torch.equal(a, b)
+        with torch.no_grad():   # what an optimizer step / a train-mode forward does: in-place updates
+            model.sa1.conv_blocks[0][0].weight.mul_(1.5)
+            model.fp1.mlp_bns[0].running_mean.add_(0.25)
+            model.final_fusion[4].bias.add_(1.0)
+        c = run()
+        assert float((c - a).abs().max()) > 1e-2
+        rowmlp._eval_operands.clear()
+        d = run()               # the same weights prepared afresh
+        assert torch.equal(c, d)
+    finally:
+        rowmlp.set_precision("fp32")
