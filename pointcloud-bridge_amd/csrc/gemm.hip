@@ -834,7 +834,9 @@ long nt_grid_x(int pro, long R, int N)
     const long ny = (N + NT_BN - 1) / NT_BN;
     static const long fwd_chip = getenv("PCB_NT_FWD_GRID") ? atol(getenv("PCB_NT_FWD_GRID")) : 768;  // tuning knobs
     static const long bwd_chip = getenv("PCB_NT_BWD_GRID") ? atol(getenv("PCB_NT_BWD_GRID")) : 512;
-    const long chip = pro <= PRO_BNACT ? fwd_chip : bwd_chip - 2 * g_shared_cus;
+    // while another kernel holds CUs (pcb_set_concurrency_hint) the persistent grids leave them alone:
+    // 3 forward / 2 backward workgroups fit a CU
+    const long chip = pro <= PRO_BNACT ? fwd_chip - 3 * g_shared_cus : bwd_chip - 2 * g_shared_cus;
     const long resident = chip / ny > 0 ? chip / ny : 1;
     return tiles < resident ? tiles : resident;
 }

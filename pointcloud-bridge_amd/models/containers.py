@@ -18,10 +18,23 @@ from .pointnet2_utils import (EnhancedFeaturePropagation, FeaturePropagation, Mu
 
 
 class _SamplingPrefetchMixin:
+    _next_xyz = None
+
     def prefetch(self, xyz):
         """Start the FPS pyramid of the NEXT batch's coordinates on a side stream (see
         pointnet2_utils.prefetch_sampling); call between forward and backward of the current batch."""
         prefetch_sampling(xyz.contiguous(), [self.sa1.npoint, self.sa2.npoint, self.sa3.npoint])
+
+    def set_next(self, xyz):
+        """Pipelined inference: the coordinates of the batch that FOLLOWS the next forward call.  That
+        call starts their coordinate-only work (prefetch) as soon as its own encoder has consumed the
+        previous prefetch, so that it runs beside the decoder instead of in front of the next pass."""
+        self._next_xyz = xyz
+
+    def _start_next(self):
+        if self._next_xyz is not None:
+            nxt, self._next_xyz = self._next_xyz, None
+            self.prefetch(nxt)
 
 
 # (npoint, radius, nsample, in_channel, mlp) -- models/model.py:17-19 == models/pointnet2.py:20-22
@@ -66,6 +79,7 @@ class PointNet2(_SamplingPrefetchMixin, nn.Module):
         l1_xyz, l1 = self.sa1(xyz, points)
         l2_xyz, l2 = self.sa2(l1_xyz, l1)
         l3_xyz, l3 = self.sa3(l2_xyz, l2)
+        self._start_next()
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, points if self.rgb_skip else None, l1)
@@ -185,6 +199,7 @@ class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):
         l1_xyz, l1 = self.sa1(xyz, feats)
         l2_xyz, l2 = self.sa2(l1_xyz, l1)
         l3_xyz, l3 = self.sa3(l2_xyz, l2)
+        self._start_next()
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, feats, l1)
@@ -246,6 +261,7 @@ class EnhancedPointNet2(_SamplingPrefetchMixin, nn.Module):
         l2 = self.geometric2(l2, l2_xyz)                                          # :133
         l3_xyz, l3 = self.sa3(l2_xyz, l2)
         l3 = self.geometric3(l3, l3_xyz)                                          # :136
+        self._start_next()
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, fused_in, l1)

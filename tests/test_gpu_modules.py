@@ -207,6 +207,31 @@ def test_sampling_prefetch_gives_identical_results(mpu):
     assert len(mpu._prefetched) == 0                     # every level was picked up
 
 
+def test_pipelined_inference_gives_identical_results(mpu):
+    """set_next(): the following batch's FPS pyramid starts beside the current pass's decoder.  Two
+    consecutive eval passes must produce exactly what two plain passes produce (same CPU-generator
+    draws in the same order, same samples)."""
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models.containers import PointNet2MSG
+    g = load_golden("model_pn2_msg")
+    xyz, colors = dev(g["xyz"]), dev(g["colors"])
+    xyz2 = (xyz * 0.9).contiguous()
+    model = build(PointNet2MSG, g["init_seed"], 5).eval()
+    for mode in ("fp32", "bf16"):
+        rowmlp.set_precision(mode)
+        try:
+            with torch.no_grad():
+                torch.manual_seed(11)
+                a1, a2 = model(xyz, colors), model(xyz2, colors)
+                torch.manual_seed(11)
+                model.set_next(xyz2)
+                b1 = model(xyz, colors)
+                b2 = model(xyz2, colors)
+            assert torch.equal(a1, b1) and torch.equal(a2, b2), mode
+        finally:
+            rowmlp.set_precision("fp32")
+
+
 def test_flat_adam_equals_torch_fused_adam():
     """parallel.FlatAdam (one flat buffer, one fused launch) == torch.optim.Adam(fused=True), bit for bit."""
     from pointcloud_bridge_amd.parallel import FlatAdam
