@@ -285,8 +285,9 @@ class _FusedStack(torch.autograd.Function):
         desc = _stack_desc(layers, widths, ybuf, R)
         ready = 0
         cache_key = None
-        if not torch.is_grad_enabled():
-            apply_concurrency_hint()  # pipelined inference: the next batch's FPS may be running beside this pass
+        # pipelined inference: the next batch's FPS may be running beside this pass; training: a hint left
+        # over from the backward pass is dropped once its event has completed
+        apply_concurrency_hint()
         if not torch.is_grad_enabled() and not any(t[6] for t in layers):
             cache_key, versions, hit = _eval_lookup(layers, layers[0][0], ("stack", Kp, perm, L))
             if hit is not None:
