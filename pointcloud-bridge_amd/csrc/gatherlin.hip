@@ -33,13 +33,6 @@ constexpr int kDwxSlabs = 32;
 
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
-__device__ __forceinline__ void unpack8(const uint4 &v, float *f)
-{
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-}
 __device__ __forceinline__ void load8(const float *p, float *f)
 {
     const float4 a = *reinterpret_cast<const float4 *>(p);

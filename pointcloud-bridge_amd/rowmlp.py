@@ -242,8 +242,9 @@ _eval_operands = {}
 
 def _eval_lookup(layers, first, extra):
     """(key, versions, (wbuf, stz) or None) for a no-grad call whose layers are all in eval mode."""
-    tensors = [t for lay in layers for t in lay[:6] if t is not None]
-    versions = tuple(t._version for t in tensors) + tuple(t.data_ptr() for t in tensors)
+    # version counters catch in-place updates (optimizer steps, load_state_dict, running statistics);
+    # the first tensor's identity (weak reference below) and address catch a replaced module
+    versions = tuple([t._version for lay in layers for t in lay[:6] if t is not None]) + (first.data_ptr(),)
     key = (id(first),) + extra
     hit = _eval_operands.get(key)
     if hit is not None and hit[0]() is first and hit[1] == versions:
