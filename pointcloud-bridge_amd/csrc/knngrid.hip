@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_grid_query_kernel(const flo
     // The k best so far as an UNSORTED set in this lane's LDS column: a qualifying candidate replaces
     // the current largest member and the column is rescanned for the new largest -- k independent
     // reads instead of a dependent shift chain (a wave runs the replacement whenever ANY of its lanes
-    // has a new member, i.e. for most candidates; sorted insertion made that 5 times dearer).
+    // has a new member, i.e. for most candidates; with a sorted insertion chain the kernel took twice as long).
     // Empty slots hold the largest key, so they are replaced first; slots beyond k hold 0 and never are.
 #pragma unroll
     for (int e = 0; e < KMAX; ++e) lst[e * kQueryThreads + t] = e < k ? ~0ull : 0ull;
