@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_grid_query_kernel(const flo
 #pragma unroll
     for (int e = 0; e < KMAX; ++e) lst[e * kQueryThreads + t] = e < k ? ~0ull : 0ull;
     unsigned long long kth = ~0ull;  // largest member = the key to beat
-    int kpos = 0;
+    int kpos = 0, filled = 0;        // the first k candidates are simply appended (no rescan until the set is full)
 
     auto scan = [&](int row, int x0, int x1) {  // cells x0..x1 of grid row `row` = one run of sorted points
         const int from = cell_start[row * nx + x0], to = cell_start[row * nx + x1 + 1];
@@ -230,7 +230,11 @@ __global__ __launch_bounds__(kQueryThreads) void knn_grid_query_kernel(const flo
             const float pd = __fadd_rn(__fmaf_rn(-2.0f, dot, q.w), c.w);
             const unsigned long long key = ((unsigned long long)sortable(pd) << 32) | (unsigned)oidx[j];
             if (key >= kth) continue;
-            lst[kpos * kQueryThreads + t] = key;
+            if (filled < k - 1) {
+                lst[filled++ * kQueryThreads + t] = key;
+                continue;
+            }
+            lst[(filled < k ? filled++ : kpos) * kQueryThreads + t] = key;
             unsigned long long m = 0;
 #pragma unroll
             for (int e = 0; e < KMAX; ++e) {
