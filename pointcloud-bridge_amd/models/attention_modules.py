@@ -29,7 +29,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import nbrmlp, ops, rowmlp, rowsf32
-from .pointnet2_utils import _channels_last, _seq_rows, side_stream
+from .pointnet2_utils import (_channels_last, _seq_rows, index_points, side_stream,  # noqa: F401
+                              square_distance)  # the reference keeps its own copies of these two (:273-309)
 
 
 def _rows_linear(x, w, b):
