@@ -56,6 +56,25 @@ def _worker(rank, world, port, tmp):
     # after the reduce every gradient is a view into the one flat, averaged buffer
     lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + bucket.flat.numel() * 4
     assert all(lo <= p.grad.data_ptr() < hi for p in model.parameters())
+    # the bench's combination: gradients packed into the flat buffer (no view re-assignment), averaged,
+    # and ONE flat fused Adam step on it -- against torch.optim.Adam on the full batch in one process
+    model.zero_grad(set_to_none=True)
+    params = [p for p in model.parameters()]
+    bucket2 = parallel.FlatGradAllReduce(params, assign_views=False)
+    opt = parallel.FlatAdam(params, lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4)
+    full2 = nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.ReLU(), nn.Linear(8, 3)).eval()
+    full2.load_state_dict(model.state_dict())
+    ref_opt = torch.optim.Adam(full2.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4)
+    for _ in range(3):
+        bucket2.zero()
+        ((model(X[mine]) - Y[mine]) ** 2).mean().backward()
+        bucket2.reduce()
+        opt.step(bucket2.flat)
+        ref_opt.zero_grad()
+        ((full2(X) - Y) ** 2).mean().backward()
+        ref_opt.step()
+    for a, b in zip(model.parameters(), full2.parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
