@@ -23,7 +23,12 @@ class _SamplingPrefetchMixin:
     def prefetch(self, xyz):
         """Start the FPS pyramid of the NEXT batch's coordinates on a side stream (see
         pointnet2_utils.prefetch_sampling); call between forward and backward of the current batch."""
-        prefetch_sampling(xyz.contiguous(), [self.sa1.npoint, self.sa2.npoint, self.sa3.npoint])
+        sas = (self.sa1, self.sa2, self.sa3)
+        balls = [((m.radius_list, m.nsample_list) if hasattr(m, "radius_list") else ([m.radius], [m.nsample]))
+                 for m in sas]
+        k = 4 if hasattr(self.fp1, "attention") else 3   # EnhancedFeaturePropagation uses 4 neighbours (:256)
+        # decoder stages: fp3 level 2 <- 3, fp2 level 1 <- 2, fp1 level 0 <- 1
+        prefetch_sampling(xyz.contiguous(), [m.npoint for m in sas], balls, [(2, 3, k), (1, 2, k), (0, 1, k)])
 
     def set_next(self, xyz):
         """Pipelined inference: the coordinates of the batch that FOLLOWS the next forward call.  That

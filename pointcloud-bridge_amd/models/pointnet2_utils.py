@@ -72,23 +72,64 @@ def side_stream(device):
     return _side_stream
 
 
-def prefetch_sampling(xyz, npoints):
+def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
     """Compute the FPS pyramid xyz -> npoints[0] -> npoints[1] -> ... on a side stream and park it
     for the next forward pass over these coordinates (SetAbstraction / MultiScaleSetAbstraction pick
-    it up by tensor identity).  Call after the forward of the current batch."""
+    it up by tensor identity).  Call after the forward of the current batch.
+
+    The other coordinate-only operators of a PointNet++ pass can ride along:
+      balls[l]    = (radii, nsamples) of the set abstraction at level l  -> its ball-query indices
+      propagation = [(fine level, coarse level, k), ...] with level 0 = xyz, level l = the l-th
+                    sampled cloud                                         -> the k-NN of each decoder stage
+    Their results (megabytes of indices) are copied into buffers this module owns -- two sets, used
+    alternately, because the backward pass of the current batch still reads the set the current
+    forward pass took -- so that no large block changes streams in the caching allocator.  They are
+    parked under the identity of the level tensors, which the forward pass receives again from
+    _sample, and picked up by _ball_indices / _nearest.  Contract: a parked result (and whatever
+    autograd saved of it) is valid until the SECOND prefetch after the one that produced it, i.e. for
+    the usual forward -> prefetch -> backward -> step loop and for pipelined inference."""
+    global _parity
     side_stream(xyz.device)
     main = torch.cuda.current_stream()
     _side_stream.wait_stream(main)
     _prefetched.clear()
+    # entries of the batch in flight stay (a pipelined inference pass starts this prefetch before its
+    # own decoder has taken its k-NN); their set of buffers is not the one written now
+    for stale in [k for k, v in _parked.items() if v[2] != _parity]:
+        del _parked[stale]
+    _parity ^= 1
     cur = xyz
+    levels = [xyz]
+
+    def park(key, res):
+        slot = (key[0], sum(1 for v in _parked.values() if v[2] == _parity), _parity)
+        held = _owned.get(slot)
+        if held is None or any(h.shape != r.shape or h.dtype != r.dtype for h, r in zip(held, res)):
+            with torch.cuda.stream(main):  # blocks of the main stream's pool, for good
+                held = _owned[slot] = tuple(torch.empty_like(r) for r in res)
+        for h, r in zip(held, res):
+            h.copy_(r)
+        ev = torch.cuda.Event()
+        ev.record(_side_stream)
+        _parked[key] = (held, ev, _parity)
+
     with torch.cuda.stream(_side_stream):
-        for npoint in npoints:
+        for l, npoint in enumerate(npoints):
             idx = farthest_point_sample(cur, npoint)
             new_xyz = index_points(cur, idx)
             ev = torch.cuda.Event()
             ev.record(_side_stream)
             _prefetched[_key(cur, npoint)] = (idx, new_xyz, ev)
+            if balls is not None and balls[l] is not None:
+                radii, nsamples = balls[l]
+                park(_ball_key(radii, nsamples, cur, new_xyz), _ball_indices_now(radii, nsamples, cur, new_xyz))
             cur = new_xyz
+            levels.append(new_xyz)
+        for fine, coarse, k in (propagation or ()):
+            park(("nn", levels[fine].data_ptr(), levels[coarse].data_ptr(), int(k)),
+                 ops.three_nn(levels[fine], levels[coarse], k))
+        ev = torch.cuda.Event()
+        ev.record(_side_stream)
     # one FPS workgroup per scene; the GEMMs beside it leave twice that many CUs alone (measured)
     ops.set_background_work(ev, 2 * xyz.shape[0])
 
@@ -169,6 +210,42 @@ def _sample(xyz, npoint):
     idx.record_stream(main)
     new_xyz.record_stream(main)
     return idx, new_xyz
+
+
+_parked = {}  # coordinate-only results of prefetch_sampling other than the FPS pyramid: key -> (tensors, event)
+_owned = {}   # their storage: (kind, ordinal, parity) -> tensors, allocated once on the main stream
+_parity = 0
+
+
+def _take_parked(key):
+    hit = _parked.pop(key, None)
+    if hit is None:
+        return None
+    res, ev, _ = hit
+    torch.cuda.current_stream().wait_event(ev)
+    return res
+
+
+def _ball_key(radii, nsamples, xyz, new_xyz):
+    return ("ball", xyz.data_ptr(), new_xyz.data_ptr(), tuple(float(r) for r in radii), tuple(int(n) for n in nsamples))
+
+
+def _ball_indices_now(radii, nsamples, xyz, new_xyz):
+    if len(radii) == 2:
+        return tuple(ops.ball_query2(list(radii), list(nsamples), xyz, new_xyz))  # two radii, one sweep
+    return tuple(ops.ball_query(r, ns, xyz, new_xyz) for r, ns in zip(radii, nsamples))
+
+
+def _ball_indices(radii, nsamples, xyz, new_xyz):
+    """Ball-query indices of every scale of a set abstraction: parked by prefetch_sampling or computed now."""
+    hit = _take_parked(_ball_key(radii, nsamples, xyz, new_xyz)) if _parked else None
+    return hit if hit is not None else _ball_indices_now(radii, nsamples, xyz, new_xyz)
+
+
+def _nearest(xyz1, xyz2, k):
+    """(d2, idx) of the k nearest xyz2 points of every xyz1 point: parked by prefetch_sampling or computed now."""
+    hit = _take_parked(("nn", xyz1.data_ptr(), xyz2.data_ptr(), int(k))) if _parked else None
+    return hit if hit is not None else ops.three_nn(xyz1, xyz2, k)
 
 
 def query_ball_point(radius, nsample, xyz, new_xyz):
@@ -265,7 +342,7 @@ class SetAbstraction(nn.Module):
         feat = None if points is None else _channels_last(points)
         B = xyz.shape[0]
         _, new_xyz = _sample(xyz, self.npoint)
-        idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+        idx, = _ball_indices([self.radius], [self.nsample], xyz, new_xyz)
         x = _grouped_mlp(self.mlp_convs, self.mlp_bns, xyz, new_xyz, feat, idx)
         return new_xyz, x.view(B, self.npoint, -1).transpose(1, 2)
 
@@ -294,11 +371,7 @@ class MultiScaleSetAbstraction(nn.Module):
         """xyz [B,N,3], points [B,C,N] or None -> new_xyz [B,S,3], [B, len(radius)*mlp[-1], S]."""
         feat = None if points is None else _channels_last(points)
         _, new_xyz = _sample(xyz, self.npoint)  # one FPS for all scales (:335)
-        if len(self.radius_list) == 2:
-            idx_list = ops.ball_query2(self.radius_list, self.nsample_list, xyz, new_xyz)
-        else:
-            idx_list = [query_ball_point(r, ns, xyz, new_xyz)
-                        for r, ns in zip(self.radius_list, self.nsample_list)]
+        idx_list = _ball_indices(self.radius_list, self.nsample_list, xyz, new_xyz)
         B = xyz.shape[0]
         outs = []
         for i, idx in enumerate(idx_list):
@@ -316,7 +389,7 @@ def _interpolate(xyz1, xyz2, points2, k):
         # reference result to reproduce, so this raises as well.
         raise RuntimeError("feature propagation from a single centroid (S == 1) fails in the reference "
                            "(shape mismatch in its repeat branch) and is not supported")
-    d2, idx = ops.three_nn(xyz1, xyz2, k)
+    d2, idx = _nearest(xyz1, xyz2, k)
     feat = _channels_last(points2)
     out = ops.three_interpolate(feat.float(), d2, idx)
     return out.to(feat.dtype)
@@ -328,7 +401,7 @@ def _propagate_rows(xyz1, xyz2, points1, points2, k):
     B, N, _ = xyz1.shape
     S, C = xyz2.shape[1], points2.shape[1]
     if rowmlp.is_bf16() and S > 1 and C % 8 == 0:
-        d2, idx = ops.three_nn(xyz1, xyz2, k)
+        d2, idx = _nearest(xyz1, xyz2, k)
         skip = None if points1 is None else _channels_last(points1).reshape(B * N, -1)
         return rowmlp.interpolate_concat(skip, _channels_last(points2), d2, idx)
     x = _interpolate(xyz1, xyz2, points2, k)
