@@ -126,8 +126,12 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
             cur = new_xyz
             levels.append(new_xyz)
         for fine, coarse, k in (propagation or ()):
-            park(("nn", levels[fine].data_ptr(), levels[coarse].data_ptr(), int(k)),
-                 ops.three_nn(levels[fine], levels[coarse], k))
+            nn_key = ("nn", levels[fine].data_ptr(), levels[coarse].data_ptr(), int(k))
+            park(nn_key, ops.three_nn(levels[fine], levels[coarse], k))
+            if rowmlp.is_bf16() and torch.is_grad_enabled():
+                # the inverted index the interpolation's backward pass reduces over (bf16 engine)
+                held_idx = _parked[nn_key][0][1]
+                park(("csr", held_idx.data_ptr()), rowmlp.build_interp_csr(held_idx, levels[coarse].shape[1]))
         ev = torch.cuda.Event()
         ev.record(_side_stream)
     # one FPS workgroup per scene; the GEMMs beside it leave twice that many CUs alone (measured)
@@ -402,8 +406,9 @@ def _propagate_rows(xyz1, xyz2, points1, points2, k):
     S, C = xyz2.shape[1], points2.shape[1]
     if rowmlp.is_bf16() and S > 1 and C % 8 == 0:
         d2, idx = _nearest(xyz1, xyz2, k)
+        csr = _take_parked(("csr", idx.data_ptr())) if _parked else None
         skip = None if points1 is None else _channels_last(points1).reshape(B * N, -1)
-        return rowmlp.interpolate_concat(skip, _channels_last(points2), d2, idx)
+        return rowmlp.interpolate_concat(skip, _channels_last(points2), d2, idx, csr)
     x = _interpolate(xyz1, xyz2, points2, k)
     if points1 is not None:
         x = torch.cat([_channels_last(points1).to(x.dtype), x], dim=-1)

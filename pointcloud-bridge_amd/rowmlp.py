@@ -730,6 +730,23 @@ def conv_rows(conv, x, out_dtype=None, out_gap=0):
     return y if out_dtype is None else y.to(out_dtype)
 
 
+def build_interp_csr(idx, S):
+    """Inverted index of an interpolation's neighbour table idx [B,N,k] (values in [0,S)): for every
+    source row the list of (target, slot) entries that read it -- (offsets [B*S+1] int64, entries
+    [B*N*k] int32).  Depends on the coordinates only, so a prefetch can build it ahead."""
+    B, N, k = idx.shape
+    dev = idx.device
+    count = torch.zeros(2, B * S, dtype=torch.int32, device=dev)  # counts | placement cursors
+    entries = torch.empty(B * N * k, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _launch("pcb_interp_csr_count", B * N * k, idx.data_ptr(), B, N, S, k, count[0].data_ptr())
+        offsets = torch.zeros(B * S + 1, dtype=torch.int64, device=dev)
+        offsets[1:] = torch.cumsum(count[0], dim=0)
+        _launch("pcb_interp_csr_fill", B * N * k, idx.data_ptr(), B, N, S, k, offsets.data_ptr(),
+                count[1].data_ptr(), entries.data_ptr())
+    return offsets, entries
+
+
 class _InterpConcatBF16(torch.autograd.Function):
     """[skip | interpolated] rows of FeaturePropagation (models/pointnet2_utils.py:191-203) written
     once, as the bf16 input buffer of the following GEMM: columns [0:D1) = skip features,
@@ -738,7 +755,7 @@ class _InterpConcatBF16(torch.autograd.Function):
     row over an inverted index (no atomics)."""
 
     @staticmethod
-    def forward(ctx, skip, feat, d2, idx):
+    def forward(ctx, skip, feat, d2, idx, offsets, entries):
         B, S, C = feat.shape
         N, k = d2.shape[1], d2.shape[2]
         D1 = 0 if skip is None else skip.shape[1]
@@ -753,37 +770,34 @@ class _InterpConcatBF16(torch.autograd.Function):
         with torch.cuda.device(dev):
             _launch("pcb_interpolate_bf16", 2 * B * N * C, feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S, C,
                     k, out.data_ptr(), dp + C, dp, w.data_ptr())
-        ctx.save_for_backward(idx, w)
+        ctx.save_for_backward(idx, w, offsets, entries)
         ctx.shape = (B, N, S, C, k, D1, dp)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        idx, w = ctx.saved_tensors
+        idx, w, offsets, entries = ctx.saved_tensors
         B, N, S, C, k, D1, dp = ctx.shape
         dev = g.device
         g = g.contiguous()
-        count = torch.zeros(2, B * S, dtype=torch.int32, device=dev)  # counts | placement cursors
-        entries = torch.empty(B * N * k, dtype=torch.int32, device=dev)
+        if offsets is None:  # not built ahead by a prefetch
+            offsets, entries = build_interp_csr(idx, S)
         gfeat = torch.empty(B, S, C, dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
-            _launch("pcb_interp_csr_count", B * N * k, idx.data_ptr(), B, N, S, k, count[0].data_ptr())
-            offsets = torch.zeros(B * S + 1, dtype=torch.int64, device=dev)
-            offsets[1:] = torch.cumsum(count[0], dim=0)
-            _launch("pcb_interp_csr_fill", B * N * k, idx.data_ptr(), B, N, S, k, offsets.data_ptr(),
-                    count[1].data_ptr(), entries.data_ptr())
             _launch("pcb_interpolate_bwd_csr_bf16", 2 * B * N * C * k, g.data_ptr(), dp + C, dp, w.data_ptr(),
                     offsets.data_ptr(), entries.data_ptr(), B, N, S, C, k, gfeat.data_ptr())
         gskip = g[:, :D1] if (D1 and ctx.needs_input_grad[0]) else None
-        return gskip, gfeat, None, None
+        return gskip, gfeat, None, None, None, None
 
 
-def interpolate_concat(skip_rows, feat_bsc, d2, idx):
+def interpolate_concat(skip_rows, feat_bsc, d2, idx, csr=None):
     """bf16 mode: (rows [B*N, pad8(D1)+C] bf16, perm) with perm = -D1 describing the column layout
-    for conv_bn_act / mlp_rows / conv_rows (0 when there is no gap).  Needs C % 8 == 0."""
+    for conv_bn_act / mlp_rows / conv_rows (0 when there is no gap).  Needs C % 8 == 0.
+    csr = build_interp_csr(idx, S) if the caller already has it (the backward pass builds it otherwise)."""
     feat = feat_bsc.to(torch.bfloat16).contiguous()
     skip = None if skip_rows is None else skip_rows.to(torch.bfloat16)
-    rows = _InterpConcatBF16.apply(skip, feat, d2.contiguous(), idx.contiguous())
+    offsets, entries = csr if csr is not None else (None, None)
+    rows = _InterpConcatBF16.apply(skip, feat, d2.contiguous(), idx.contiguous(), offsets, entries)
     d1 = 0 if skip is None else skip.shape[1]
     return rows, (-d1 if d1 % 8 else 0)
 
