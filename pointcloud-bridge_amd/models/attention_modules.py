@@ -124,14 +124,29 @@ class BridgeStructureEncoding(nn.Module):
         pyramid (pointnet2_utils.prefetch_sampling), while the current batch is in its backward
         pass; rows() picks it up by tensor identity.  Same results, only earlier."""
         xyz = xyz.float().contiguous()
+        main = torch.cuda.current_stream()
         side = side_stream(xyz.device)
-        side.wait_stream(torch.cuda.current_stream())
+        side.wait_stream(main)
         _geometry.clear()
+        # The results (rel alone is 100 MB at B=16, N=16384, k=32) are copied into two alternating sets
+        # of buffers this module owns -- the backward pass of the batch in flight still reads the
+        # other set -- so that no large block changes streams in the caching allocator (see
+        # pointnet2_utils.prefetch_sampling for the measurement behind this).
+        self._parity = getattr(self, "_parity", 0) ^ 1
         with torch.cuda.stream(side):
-            per_point, rel = self.geometry(xyz)
+            res = self.geometry(xyz)
+            held = self._owned.get(self._parity) if hasattr(self, "_owned") else None
+            if held is None or any(h.shape != r.shape for h, r in zip(held, res)):
+                with torch.cuda.stream(main):
+                    held = tuple(torch.empty_like(r) for r in res)
+                if not hasattr(self, "_owned"):
+                    self._owned = {}
+                self._owned[self._parity] = held
+            for h, r in zip(held, res):
+                h.copy_(r)
             ev = torch.cuda.Event()
             ev.record(side)
-        _geometry[self._geometry_key(xyz)] = (per_point, rel, ev)
+        _geometry[self._geometry_key(xyz)] = (held[0], held[1], ev)
 
     def rows(self, xyz):
         """xyz [B,N,3] -> code rows [B*N, channels] (channels-last)."""
@@ -143,10 +158,7 @@ class BridgeStructureEncoding(nn.Module):
             per_point, rel = self.geometry(xyz)
         else:
             per_point, rel, ev = hit
-            main = torch.cuda.current_stream()
-            main.wait_event(ev)
-            per_point.record_stream(main)
-            rel.record_stream(main)
+            torch.cuda.current_stream().wait_event(ev)
         conv0, bn, _, conv1 = self.structure_mlp
         a = self.abs_pos_dim
         w = conv0.weight.view(self.channels, self.total_dim)
