@@ -182,7 +182,7 @@ def main():
 
     def infer_step():
         with torch.no_grad():
-            if prefetch:
+            if prefetch and hasattr(model, "set_next"):
                 model.set_next(xyz)  # pipelined serving: the next batch's FPS pyramid runs beside this pass's decoder
             return loss_of(model(xyz, colors))
 
@@ -321,7 +321,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": vs_baseline, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} {('fwd+' + ('CE' if args.loss == 'ce' else 'BridgeStructureLoss') + '+bwd+grad-allreduce+Adam') if args.mode == 'train' else ('eval-mode forward+CE' + (', next batch FPS pipelined' if prefetch else ''))}, B={B} scenes/GPU x N={N} pts, "
+            "config": {"workload": f"{args.model} {('fwd+' + ('CE' if args.loss == 'ce' else 'BridgeStructureLoss') + '+bwd+grad-allreduce+Adam') if args.mode == 'train' else ('eval-mode forward+CE' + (', next batch FPS pipelined' if (prefetch and hasattr(model, 'set_next')) else ''))}, B={B} scenes/GPU x N={N} pts, "
                                    f"unit-ball clouds (configs[1] of BASELINE.json)",
                        "scenes_per_gpu": B, "points_per_scene": N, "parallelism": f"dp{world} (scenes sharded)",
                        "loss": float(loss.detach()),

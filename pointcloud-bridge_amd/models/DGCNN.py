@@ -54,12 +54,46 @@ class DGCNN(nn.Module):
             idx = ops.knn(xt, k)
         return ops.edge_features(xt, idx).permute(0, 3, 1, 2)
 
+    # -- the first graph depends on the coordinates only -----------------------------------------
+    def prefetch(self, xyz):
+        """Build the coordinate graph of the NEXT batch on a side stream while the current batch is in
+        its backward pass (the three feature-space graphs cannot move: they depend on the weights).
+        The indices land in one of two buffers this module owns, used alternately -- the backward pass
+        of the batch in flight still reads the other one -- and forward() picks them up by tensor identity."""
+        from .pointnet2_utils import side_stream
+        B, N, _ = xyz.shape
+        k = min(self.k, N - 1)
+        main = torch.cuda.current_stream()
+        side = side_stream(xyz.device)
+        side.wait_stream(main)
+        self._parity = getattr(self, "_parity", 0) ^ 1
+        if not hasattr(self, "_owned"):
+            self._owned = {}
+        with torch.cuda.stream(side):
+            idx = ops.knn(xyz[:, :, :3].contiguous().float(), k)
+            held = self._owned.get(self._parity)
+            if held is None or held.shape != idx.shape:
+                with torch.cuda.stream(main):
+                    held = self._owned[self._parity] = torch.empty_like(idx)
+            held.copy_(idx)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._graph0 = ((xyz.data_ptr(), xyz._version, tuple(xyz.shape), k), held, ev)
+
+    def _first_graph(self, xyz, x0, k):
+        hit, self._graph0 = getattr(self, "_graph0", None), None
+        if hit is not None and hit[0] == (xyz.data_ptr(), xyz._version, tuple(xyz.shape), k):
+            torch.cuda.current_stream().wait_event(hit[2])
+            return hit[1]
+        return None
+
     # -- forward ------------------------------------------------------------------------------
-    def _edge_conv(self, block, x, k):
+    def _edge_conv(self, block, x, k, idx=None):
         """x [B,N,D] channels-last -> [B,N,Cout]: kNN graph, edge features, conv+BN+LeakyReLU, max."""
         B, N, D = x.shape
         xf = x.float()
-        idx = ops.knn(xf, k)  # the graph is always built from fp32 distances
+        if idx is None:
+            idx = ops.knn(xf, k)  # the graph is always built from fp32 distances
         if ((x.requires_grad or not torch.is_grad_enabled()) and D >= 32 and D % 8 == 0
                 and rowmlp.gathered_ok([block[0]], [block[1]])):
             # W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i: per-point products, gathered by the graph
@@ -79,7 +113,7 @@ class DGCNN(nn.Module):
         B, N, _ = xyz.shape
         x0 = xyz[:, :, :3].contiguous()
         k = min(self.k, N - 1)  # reference :131
-        x1 = self._edge_conv(self.conv1, x0, k)
+        x1 = self._edge_conv(self.conv1, x0, k, self._first_graph(xyz, x0, k))
         x2 = self._edge_conv(self.conv2, x1, k)
         x3 = self._edge_conv(self.conv3, x2, k)
         x4 = self._edge_conv(self.conv4, x3, k)
