@@ -18,6 +18,7 @@ xyz, colors, labels = bench.synthetic_batch(16 if cdim == 1 else 8, 16384 if cdi
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WATCH = ("copy_", "_to_copy", "fill_", "zero_", "zeros", "add", "cat", "clone", "constant_pad_nd", "contiguous", "sum", "mul", "index")
 sites = collections.Counter()
+volume = collections.Counter()
 
 class Log(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -28,7 +29,11 @@ class Log(TorchDispatchMode):
                 if root in fs.filename and "tools/" not in fs.filename:
                     frame = f"{fs.filename.replace(root + '/', '')}:{fs.lineno} {fs.line}"
                     break
+            out = func(*args, **(kwargs or {}))
+            first = out if torch.is_tensor(out) else (args[0] if args and torch.is_tensor(args[0]) else None)
             sites[(name, frame)] += 1
+            volume[(name, frame)] += 0 if first is None else first.numel() * first.element_size()
+            return out
         return func(*args, **(kwargs or {}))
 
 def step():
@@ -37,5 +42,5 @@ for _ in range(2): step()
 with Log():
     step()
 torch.cuda.synchronize()
-for (name, frame), n in sorted(sites.items(), key=lambda kv: (-kv[1], kv[0]))[:70]:
-    print(f"{n:4d}x {name:18s} {frame[:150]}")
+for (name, frame), n in sorted(sites.items(), key=lambda kv: (-volume[kv[0]], kv[0]))[:40]:
+    print(f"{volume[(name, frame)] / 1e6:8.1f} MB {n:4d}x {name:18s} {frame[:140]}")
