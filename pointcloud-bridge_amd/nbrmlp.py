@@ -10,7 +10,7 @@ reduce pass + finalize + apply pass (the same BatchNorm-backward algebra as the 
 import torch
 
 from . import _lib
-from .ops import _launch
+from .ops import _launch, on_device
 from .rowmlp import _bn_bookkeeping, _counter
 
 
@@ -27,7 +27,7 @@ class _NeighbourMLP(torch.autograd.Function):
         consts = torch.empty(4, C, dtype=torch.float32, device=dev)  # scale | shift | mean | invstd
         out = torch.empty(P, C, dtype=torch.float32, device=dev)
         arg = torch.empty(P, C, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             sums = None
             if training:
                 sums = torch.empty(parts, 2, C, dtype=torch.float32, device=dev)
@@ -60,7 +60,7 @@ class _NeighbourMLP(torch.autograd.Function):
         dwrp = torch.empty(parts, C, 3, dtype=torch.float32, device=dev)
         pq = torch.empty(4, C, dtype=torch.float32, device=dev)  # p | q | dgamma | dbeta
         dbase = torch.empty(P, C, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_nbr_mlp_backward_reduce", P * k * C * C, base.data_ptr(), rel.data_ptr(), P, k, C,
                     wr.data_ptr(), consts[0].data_ptr(), consts[1].data_ptr(), consts[2].data_ptr(),
                     consts[3].data_ptr(), w2.data_ptr(), g.data_ptr(), arg.data_ptr(), sums.data_ptr(),

@@ -17,7 +17,30 @@ from . import _lib
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw HIP stream handle of torch's current stream (the direct binding: a quarter of the cost of
+    torch.cuda.current_stream().cuda_stream, and this runs once per launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class _NoContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
+
+
+def on_device(dev):
+    """`with on_device(t.device):` around launches -- torch.cuda.device(dev) only when `dev` is not
+    the current device already (one process per GPU: it always is, and entering / leaving the real
+    context manager costs ~5 us, ~100 times per training step)."""
+    idx = dev.index
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NO_CONTEXT
+    return torch.cuda.device(dev)
 
 
 # Live timing of the roofline kernel family (bench.py): libpcb_hip.so records HIP events on the
@@ -76,8 +99,15 @@ def apply_concurrency_hint():
 def _launch(name, units, *args):
     """Call entry point `name` of libpcb_hip.so on the current stream; raise on a bad status.
     (`units` documents the call's work at the call site; timing lives in the library.)"""
-    status = getattr(_lib.load(), name)(*args, _stream())
-    _lib.check(status, name)
+    fn = _entry.get(name)
+    if fn is None or _lib._lib is None:  # first use, or the library handle was dropped: (re)load, fail loudly
+        fn = _entry[name] = getattr(_lib.load(), name)
+    status = fn(*args, torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    if status:
+        _lib.check(status, name)
+
+
+_entry = {}  # bound entry points of libpcb_hip.so
 
 
 def _need_cuda(*tensors):
@@ -122,7 +152,7 @@ def square_distance(src, dst):
     B, N, _ = src.shape
     M = dst.shape[1]
     out = torch.empty(B, N, M, dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
+    with on_device(src.device):
         _launch("pcb_square_distance", B * N * M, src.data_ptr(), dst.data_ptr(), B, N, M, out.data_ptr())
     return out
 
@@ -136,7 +166,7 @@ def furthest_point_sample(xyz, npoint, start_idx):
     if start_idx.shape != (B,):
         raise ValueError(f"start_idx must be [B]={B}, got {tuple(start_idx.shape)}")
     out = torch.empty(B, int(npoint), dtype=torch.int64, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with on_device(xyz.device):
         _launch("pcb_fps", B * N * int(npoint), xyz.data_ptr(), B, N, int(npoint), start_idx.data_ptr(), out.data_ptr())
     return out
 
@@ -144,7 +174,7 @@ def furthest_point_sample(xyz, npoint, start_idx):
 def furthest_point_sample_into(xyz, start_idx, out_idx):
     """pcb_fps writing into a caller-owned [B,S] int64 tensor (static buffers of captured steps)."""
     B, N, _ = xyz.shape
-    with torch.cuda.device(xyz.device):
+    with on_device(xyz.device):
         _launch("pcb_fps", B * N * out_idx.shape[1], xyz.data_ptr(), B, N, out_idx.shape[1], start_idx.data_ptr(),
                 out_idx.data_ptr())
     return out_idx
@@ -154,7 +184,7 @@ def gather_rows_into(points, idx, out):
     """pcb_gather_rows (no autograd) writing into a caller-owned [B,M,C] fp32 tensor."""
     B, N, C = points.shape
     M = idx.shape[1]
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         _launch("pcb_gather_rows", B * M * C, points.data_ptr(), idx.data_ptr(), B, N, C, M, out.data_ptr())
     return out
 
@@ -176,7 +206,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
         # the reference fails here too (mask/tensor shape mismatch at pointnet2_utils.py:110)
         raise IndexError(f"nsample ({nsample}) exceeds the number of points ({N})")
     out = torch.empty(B, S, nsample, dtype=torch.int64, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with on_device(xyz.device):
         _launch("pcb_ball_query", B * S * N, xyz.data_ptr(), new_xyz.data_ptr(), B, N, S, _r2(radius), nsample, out.data_ptr())
     return out
 
@@ -192,7 +222,7 @@ def ball_query2(radii, nsamples, xyz, new_xyz):
         raise IndexError(f"nsample ({max(na, nb)}) exceeds the number of points ({N})")
     oa = torch.empty(B, S, na, dtype=torch.int64, device=xyz.device)
     ob = torch.empty(B, S, nb, dtype=torch.int64, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with on_device(xyz.device):
         _launch("pcb_ball_query2", B * S * N, xyz.data_ptr(), new_xyz.data_ptr(), B, N, S, _r2(ra), na, oa.data_ptr(), _r2(rb), nb, ob.data_ptr())
     return oa, ob
 
@@ -209,7 +239,7 @@ def three_nn(xyz1, xyz2, k=3):
         raise ValueError(f"three_nn needs 1 <= k <= 4 and S >= k (k={k}, S={S})")
     d2 = torch.empty(B, N, k, dtype=torch.float32, device=xyz1.device)
     idx = torch.empty(B, N, k, dtype=torch.int64, device=xyz1.device)
-    with torch.cuda.device(xyz1.device):
+    with on_device(xyz1.device):
         _launch("pcb_three_nn", B * N * S, xyz1.data_ptr(), xyz2.data_ptr(), B, N, S, k, d2.data_ptr(), idx.data_ptr())
     return d2, idx
 
@@ -228,7 +258,7 @@ def knn(x_bnd, k):
         raise ValueError(f"knn supports 1 <= k <= 32 and D <= 128 (k={k}, D={D})")
     out = torch.empty(B, N, k, dtype=torch.int64, device=x.device)
     norms = torch.empty(B, N, dtype=torch.float32, device=x.device)  # |x|^2 scratch of the kernel
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         if D == 3 and _GRID_KNN:
             # coordinates: the grid search of csrc/knngrid.hip (same output as the all-pairs kernel)
             ws = torch.empty(_lib.load().pcb_knn_xyz_workspace(B, N), dtype=torch.uint8, device=x.device)
@@ -261,7 +291,7 @@ def structure_features(xyz, idx, with_offsets=True):
         raise ValueError(f"structure_features supports 2 <= k <= 32 (k={k})")
     feat = torch.empty(B, N, 13, dtype=torch.float32, device=x.device)
     rel = torch.empty(B, N, k, 3, dtype=torch.float32, device=x.device) if with_offsets else None
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         _launch("pcb_structure_features", B * N * k, x.data_ptr(), nb.data_ptr(), B, N, k,
                 feat.data_ptr(), 0 if rel is None else rel.data_ptr())
     return feat, rel
@@ -276,7 +306,7 @@ class _GatherRows(torch.autograd.Function):
         B, N, C = points.shape
         M = idx_flat.shape[1]
         out = torch.empty(B, M, C, dtype=torch.float32, device=points.device)
-        with torch.cuda.device(points.device):
+        with on_device(points.device):
             _launch("pcb_gather_rows", B * M * C, points.data_ptr(), idx_flat.data_ptr(), B, N, C, M, out.data_ptr())
         ctx.save_for_backward(idx_flat)
         ctx.shape = (B, N, C, M)
@@ -288,7 +318,7 @@ class _GatherRows(torch.autograd.Function):
         B, N, C, M = ctx.shape
         g = g.contiguous()
         gp = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with on_device(g.device):
             _launch("pcb_gather_rows_bwd", B * M * C, g.data_ptr(), idx_flat.data_ptr(), B, N, C, M, gp.data_ptr())
         return gp, None
 
@@ -314,7 +344,7 @@ class _GroupPoints(torch.autograd.Function):
         S, ns = idx.shape[1], idx.shape[2]
         C = 0 if feat is None else feat.shape[2]
         out = torch.empty(B, S, ns, 3 + C, dtype=torch.float32, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with on_device(xyz.device):
             _launch("pcb_group_points", B * S * ns * (3 + C),  xyz.data_ptr(), new_xyz.data_ptr(), 0 if feat is None else feat.data_ptr(), idx.data_ptr(), B, N, S, ns, C, out.data_ptr())
         ctx.save_for_backward(idx)
         ctx.shape = (B, N, S, ns, C)
@@ -328,7 +358,7 @@ class _GroupPoints(torch.autograd.Function):
             return None, None, None, None
         g = g.contiguous()
         gf = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with on_device(g.device):
             _launch("pcb_group_points_bwd", B * S * ns * C, g.data_ptr(), idx.data_ptr(), B, N, S, ns, C, gf.data_ptr())
         return None, None, gf, None
 
@@ -356,7 +386,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         N, k = d2.shape[1], d2.shape[2]
         out = torch.empty(B, N, C, dtype=torch.float32, device=feat.device)
         w = torch.empty(B, N, k, dtype=torch.float32, device=feat.device)
-        with torch.cuda.device(feat.device):
+        with on_device(feat.device):
             _launch("pcb_interpolate", B * N * C, feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S, C, k, out.data_ptr(), w.data_ptr())
         ctx.save_for_backward(w, idx)
         ctx.shape = (B, N, S, C, k)
@@ -368,7 +398,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         B, N, S, C, k = ctx.shape
         g = g.contiguous()
         gf = torch.zeros(B, S, C, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with on_device(g.device):
             _launch("pcb_interpolate_bwd", B * N * C, g.data_ptr(), w.data_ptr(), idx.data_ptr(), B, N, S, C, k, gf.data_ptr())
         return gf, None, None
 
@@ -392,7 +422,7 @@ class _EdgeFeatures(torch.autograd.Function):
         B, N, D = x.shape
         k = idx.shape[2]
         out = torch.empty(B, N, k, 2 * D, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             _launch("pcb_edge_features", B * N * k * 2 * D, x.data_ptr(), idx.data_ptr(), B, N, D, k, out.data_ptr())
         ctx.save_for_backward(idx)
         ctx.shape = (B, N, D, k)
@@ -404,7 +434,7 @@ class _EdgeFeatures(torch.autograd.Function):
         B, N, D, k = ctx.shape
         g = g.contiguous()
         gx = torch.zeros(B, N, D, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with on_device(g.device):
             _launch("pcb_edge_features_bwd", B * N * k * 2 * D, g.data_ptr(), idx.data_ptr(), B, N, D, k, gx.data_ptr())
         return gx, None
 

@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import _launch, apply_concurrency_hint
+from .ops import _launch, apply_concurrency_hint, on_device
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 _PRECISION = "fp32"
@@ -115,7 +115,7 @@ class _LinearBNAct(torch.autograd.Function):
         y = torch.mm(x, wp.t())
         stats = torch.zeros(6, C, dtype=torch.float32, device=dev)  # sums(2) | scale | shift | mean | invstd
         sums, scale, shift, mean, invstd = stats[0:2], stats[2], stats[3], stats[4], stats[5]
-        with torch.cuda.device(dev):
+        with on_device(dev):
             if training:
                 _launch("pcb_colstats_bf16", R * C, y.data_ptr(), R, C, sums.data_ptr())
             _launch("pcb_bn_finalize", C, sums.data_ptr(), 1, R, 0, C,
@@ -150,7 +150,7 @@ class _LinearBNAct(torch.autograd.Function):
         scale, shift, mean, invstd = stats[2], stats[3], stats[4], stats[5]
         bsums = torch.zeros(2, C, dtype=torch.float32, device=dev)
         dy = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             if pool:
                 g32 = g.float().contiguous()
                 _launch("pcb_bn_act_max_bwd_bf16", R * C, g32.data_ptr(), arg.data_ptr(), y.data_ptr(),
@@ -304,7 +304,7 @@ class _FusedStack(torch.autograd.Function):
         else:
             out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
             arg = None
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, x.data_ptr(), R, Kp, perm, act, pool, int(need_dx) | ready,
                     int(stat_repeat), 0, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
                     0 if arg is None else arg.data_ptr())
@@ -349,7 +349,7 @@ class _FusedStack(torch.autograd.Function):
         parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
         apply_concurrency_hint()
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_mlp_stack_backward", 0, L, desc, x.data_ptr(), g.data_ptr(),
                     0 if arg is None else arg.data_ptr(), R, Kp, perm, act, pool, int(need_dx), 0, wbuf.data_ptr(),
                     stz.data_ptr(), parts.data_ptr(), ws.data_ptr(), 0 if dzbuf is None else dzbuf.data_ptr(),
@@ -372,7 +372,7 @@ class _PointLinear(torch.autograd.Function):
         wt = torch.empty(K, C, dtype=torch.bfloat16, device=dev) if x.requires_grad else None
         out = torch.empty(n, C, dtype=torch.float32, device=dev)
         desc = (ctypes.c_longlong * 8)(w.data_ptr(), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), C, K, K, 0, 0)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_prep_weights_bf16", C * K, 1, desc)
             _launch("pcb_gemm_nt_f32out_bf16", n * (K + 2 * C), x.data_ptr(), wp.data_ptr(), n, C, K, out.data_ptr())
         ctx.save_for_backward(x, wt)
@@ -388,7 +388,7 @@ class _PointLinear(torch.autograd.Function):
         gb = g.to(torch.bfloat16).contiguous()
         lib = _lib.load()
         dw = dx = None
-        with torch.cuda.device(dev):
+        with on_device(dev):
             if ctx.needs_input_grad[1]:
                 dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
                 ws = torch.empty(lib.pcb_gemm_tn_workspace(n, C, K), dtype=torch.float32, device=dev)
@@ -457,7 +457,7 @@ class _GatheredStack(torch.autograd.Function):
         else:
             out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
             arg = None
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, 0, R, 0, 0, act, pool, ready, 1, gather,
                     wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
                     0 if arg is None else arg.data_ptr())
@@ -507,7 +507,7 @@ class _GatheredStack(torch.autograd.Function):
         parts = torch.empty(max(_MAX_PARTS, 1024) * 2 * max(widths), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
         apply_concurrency_hint()
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_mlp_stack_backward", 0, L, desc, 0, g.data_ptr(), 0 if arg is None else arg.data_ptr(), R, 0,
                     0, act, pool, 0, gather, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), ws.data_ptr(),
                     0 if dzbuf is None else dzbuf.data_ptr(), 0)
@@ -679,7 +679,7 @@ class _LinearBias(torch.autograd.Function):
             wt = torch.empty(kp, npad, dtype=torch.bfloat16, device=dev) if need_dx else None
             bp = torch.empty(npad, dtype=torch.float32, device=dev)
         y = torch.empty(R, npad, dtype=torch.bfloat16, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             if hit is None:
                 _launch("pcb_prep_linear_bias_bf16", npad * kp, w.data_ptr(), 0 if bias is None else bias.data_ptr(), n, k,
                         npad, kp, int(out_gap), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), bp.data_ptr())
@@ -704,7 +704,7 @@ class _LinearBias(torch.autograd.Function):
         lib = _lib.load()
         ws = torch.empty(lib.pcb_gemm_tn_workspace(R, npad, kp), dtype=torch.float32, device=dev)
         sums = torch.zeros(2, npad, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             if wt is not None:
                 dx = torch.empty(R, kp, dtype=torch.bfloat16, device=dev)
                 _launch("pcb_gemm_nt_bf16", 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 0, 0, wt.data_ptr(),
@@ -738,7 +738,7 @@ def build_interp_csr(idx, S):
     dev = idx.device
     count = torch.zeros(2, B * S, dtype=torch.int32, device=dev)  # counts | placement cursors
     entries = torch.empty(B * N * k, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _launch("pcb_interp_csr_count", B * N * k, idx.data_ptr(), B, N, S, k, count[0].data_ptr())
         offsets = torch.zeros(B * S + 1, dtype=torch.int64, device=dev)
         offsets[1:] = torch.cumsum(count[0], dim=0)
@@ -767,7 +767,7 @@ class _InterpConcatBF16(torch.autograd.Function):
             if dp > D1:
                 out[:, D1:dp] = 0
         w = torch.empty(B, N, k, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_interpolate_bf16", 2 * B * N * C, feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S, C,
                     k, out.data_ptr(), dp + C, dp, w.data_ptr())
         ctx.save_for_backward(idx, w, offsets, entries)
@@ -783,7 +783,7 @@ class _InterpConcatBF16(torch.autograd.Function):
         if offsets is None:  # not built ahead by a prefetch
             offsets, entries = build_interp_csr(idx, S)
         gfeat = torch.empty(B, S, C, dtype=torch.bfloat16, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_interpolate_bwd_csr_bf16", 2 * B * N * C * k, g.data_ptr(), dp + C, dp, w.data_ptr(),
                     offsets.data_ptr(), entries.data_ptr(), B, N, S, C, k, gfeat.data_ptr())
         gskip = g[:, :D1] if (D1 and ctx.needs_input_grad[0]) else None
@@ -812,7 +812,7 @@ class _BNActRows(torch.autograd.Function):
         dev = y.device
         stats = torch.zeros(6, C, dtype=torch.float32, device=dev)  # sums(2) | scale | shift | mean | invstd
         out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             if training:
                 _launch("pcb_colstats_bf16", R * C, y.data_ptr(), R, C, stats[0:2].data_ptr())
             _launch("pcb_bn_finalize", C, stats[0:2].data_ptr(), 1, R, 0, C,
@@ -836,7 +836,7 @@ class _BNActRows(torch.autograd.Function):
         bsums = torch.zeros(2, C, dtype=torch.float32, device=dev)
         dy = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
         gb = g.to(torch.bfloat16).contiguous()
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _launch("pcb_bn_act_bwd_bf16", R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
                     stats[4].data_ptr(), stats[5].data_ptr(), R, C, act, training, bsums.data_ptr(), dy.data_ptr())
         return (dy, bsums[1].clone() if has_affine else None, bsums[0].clone() if has_affine else None,
@@ -849,7 +849,7 @@ class _Gate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, a):
         out = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             _launch("pcb_gate_bf16", x.numel(), x.data_ptr(), a.data_ptr(), out.data_ptr(), x.numel())
         ctx.save_for_backward(x, a)
         return out
@@ -859,7 +859,7 @@ class _Gate(torch.autograd.Function):
         x, a = ctx.saved_tensors
         g = g.to(torch.bfloat16).contiguous()
         dx, da = torch.empty_like(x), torch.empty_like(a)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             _launch("pcb_gate_bwd_bf16", 3 * x.numel(), g.data_ptr(), x.data_ptr(), a.data_ptr(), dx.data_ptr(),
                     da.data_ptr(), x.numel())
         return dx, da
@@ -922,7 +922,7 @@ class _GroupRowsBF16(torch.autograd.Function):
         if feat is not None:
             feat = feat.to(torch.bfloat16).contiguous()
         out = torch.empty(B * S * ns, kp, dtype=torch.bfloat16, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with on_device(xyz.device):
             _launch("pcb_group_rows_bf16", B * S * ns * kp, xyz.data_ptr(), new_xyz.data_ptr(),
                     0 if feat is None else feat.data_ptr(), idx.data_ptr(), B, N, S, ns, C, kp, out.data_ptr())
         ctx.save_for_backward(idx)
@@ -937,7 +937,7 @@ class _GroupRowsBF16(torch.autograd.Function):
             return None, None, None, None
         g = g.contiguous()
         gf = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with on_device(g.device):
             _launch("pcb_group_rows_bf16_bwd", B * S * ns * C, g.data_ptr(), idx.data_ptr(), B, N, S, ns, C, kp,
                     gf.data_ptr())
         return None, None, gf, None

@@ -7,7 +7,7 @@ summed here).  GPU only, fp32.
 import torch
 
 from . import _lib
-from .ops import _launch
+from .ops import _launch, on_device
 
 MAX_CHANNELS = 64
 
@@ -19,7 +19,7 @@ class _RowsLinear(torch.autograd.Function):
         Co = w.shape[0]
         x, w = x.contiguous(), w.contiguous()
         y = torch.empty(P, Co, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             _launch("pcb_rows_linear_f32", P * Ci * Co, x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(),
                     P, Ci, Co, y.data_ptr())
         ctx.save_for_backward(x, w)
@@ -33,7 +33,7 @@ class _RowsLinear(torch.autograd.Function):
         Co = w.shape[0]
         g = g.contiguous().float()
         dx = dw = db = None
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(P, Ci, dtype=torch.float32, device=x.device)
                 _launch("pcb_rows_linear_dgrad_f32", P * Ci * Co, g.data_ptr(), w.data_ptr(), P, Ci, Co, dx.data_ptr())
