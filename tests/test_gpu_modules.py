@@ -220,14 +220,17 @@ def test_pipelined_inference_gives_identical_results(mpu):
     for mode in ("fp32", "bf16"):
         rowmlp.set_precision(mode)
         try:
+            xyz3 = (xyz * 0.8).contiguous()
             with torch.no_grad():
                 torch.manual_seed(11)
-                a1, a2 = model(xyz, colors), model(xyz2, colors)
+                plain = [model(c, colors) for c in (xyz, xyz2, xyz3)]
                 torch.manual_seed(11)
-                model.set_next(xyz2)
-                b1 = model(xyz, colors)
-                b2 = model(xyz2, colors)
-            assert torch.equal(a1, b1) and torch.equal(a2, b2), mode
+                piped = []
+                for cur, nxt in ((xyz, xyz2), (xyz2, xyz3), (xyz3, None)):
+                    if nxt is not None:
+                        model.set_next(nxt)  # first pass: started behind its encoder; second: at its top
+                    piped.append(model(cur, colors))
+            assert all(torch.equal(a, b) for a, b in zip(plain, piped)), mode
         finally:
             rowmlp.set_precision("fp32")
 
