@@ -596,3 +596,52 @@ def test_eval_operand_cache_is_transparent_and_invalidated_by_updates():
         assert torch.equal(c, d)
     finally:
         rowmlp.set_precision("fp32")
+
+
+def test_training_with_side_stream_prefetch_equals_training_without():
+    """Two forward/backward passes with the next batch's coordinate-only work (FPS pyramid, ball queries,
+    decoder k-NN, inverted index of the interpolation) prefetched on the side stream into the
+    module-owned double buffers: the logits must equal the plain sequence bit for bit, the gradients up
+    to the summation order of the scatter atomics (the plain sequence repeated differs from itself by
+    the same amount)."""
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models.containers import PointNet2MSG
+    rowmlp.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(4)
+        batches = []
+        for _ in range(2):
+            v = torch.randn(2, 2048, 3, generator=g)
+            xyz = (v / v.norm(dim=-1, keepdim=True) * torch.rand(2, 2048, 1, generator=g) ** (1 / 3)).cuda()
+            batches.append((xyz, torch.rand(2, 2048, 3, generator=g).cuda(), torch.randint(0, 5, (2, 2048), generator=g).cuda()))
+        torch.manual_seed(2)
+        model = PointNet2MSG(5).cuda().train()
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.eval()
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+
+        def run(prefetch):
+            model.load_state_dict(state)   # running statistics back to the start
+            torch.manual_seed(17)          # CPU generator: FPS start indices
+            logits, grads = [], []
+            for i, (xyz, colors, labels) in enumerate(batches):
+                model.zero_grad(set_to_none=True)
+                out = model(xyz, colors).float()
+                if prefetch and i + 1 < len(batches):
+                    model.prefetch(batches[i + 1][0])
+                F.cross_entropy(out, labels).backward()
+                logits.append(out.detach().clone())
+                grads.append(torch.cat([p.grad.reshape(-1).float() for p in model.parameters() if p.grad is not None]))
+            return logits, grads
+
+        la, ga = run(False)
+        lr, gr = run(False)
+        lb, gb = run(True)
+        for a, b in zip(la, lb):
+            assert torch.equal(a, b)
+        for a, r, b in zip(ga, gr, gb):
+            noise = float((a - r).norm() / a.norm())
+            assert float((a - b).norm() / a.norm()) <= 3 * noise + 1e-4, noise
+    finally:
+        rowmlp.set_precision("fp32")
