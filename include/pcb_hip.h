@@ -367,7 +367,7 @@ int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, i
  * Query pcb_gemm_nt_partials AFTER setting the hint: the slab count follows the grid. */
 int pcb_set_concurrency_hint(int busy_cus);
 
-/* Number of per-workgroup statistics slabs pcb_gemm_nt_bf16 writes for these sizes. */
+/* Number of per-workgroup statistics slabs pcb_gemm_nt_bf16 writes for these sizes (never more than 768). */
 int pcb_gemm_nt_partials(int pro, long R, int N);
 
 /* dW[M,N] (fp32, overwritten) = A'[R,M]^T . B'[R,N].

@@ -828,12 +828,22 @@ long g_shared_cus = 0;
 // Workgroups along x of a gemm_nt launch (= slabs of its partials buffer): persistent over row
 // tiles, as many as are resident at once -- 3 per CU for the forward prologues, 2 for the
 // register-heavier backward ones (see the launch bounds of gemm_nt_kernel).
+// Tuning knobs for the persistent grids, clamped to [64, 768]: callers size their statistics slabs
+// for at most 768 workgroups (the documented upper bound of pcb_gemm_nt_partials); a larger grid
+// would write past them.
+long grid_knob(const char *name, long def)
+{
+    const char *e = getenv(name);
+    const long v = e ? atol(e) : def;
+    return v < 64 ? 64L : (v > 768 ? 768L : v);
+}
+
 long nt_grid_x(int pro, long R, int N)
 {
     const long tiles = (R + NT_BM - 1) / NT_BM;
     const long ny = (N + NT_BN - 1) / NT_BN;
-    static const long fwd_chip = getenv("PCB_NT_FWD_GRID") ? atol(getenv("PCB_NT_FWD_GRID")) : 768;  // tuning knobs
-    static const long bwd_chip = getenv("PCB_NT_BWD_GRID") ? atol(getenv("PCB_NT_BWD_GRID")) : 512;
+    static const long fwd_chip = grid_knob("PCB_NT_FWD_GRID", 768);
+    static const long bwd_chip = grid_knob("PCB_NT_BWD_GRID", 512);
     // while another kernel holds CUs (pcb_set_concurrency_hint) the persistent grids leave them alone:
     // 3 forward / 2 backward workgroups fit a CU
     const long chip = pro <= PRO_BNACT ? fwd_chip - 3 * g_shared_cus : bwd_chip - 2 * g_shared_cus;
@@ -951,7 +961,7 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
     if (pro >= PRO_DY && !sums && N > NT_BN && K <= 256) {
         // wide input gradient: transformed A tile resident in LDS, column tiles walked inside
         const long tiles = (R + AR_BM - 1) / AR_BM;
-        static const long ares_base = getenv("PCB_NT_BWD_GRID") ? atol(getenv("PCB_NT_BWD_GRID")) : 512;
+        static const long ares_base = grid_knob("PCB_NT_BWD_GRID", 512);
         const long ares_chip = ares_base - 2 * g_shared_cus;
         const dim3 grid((unsigned)(tiles < ares_chip ? tiles : ares_chip));
         if (pro == PRO_DY) {
