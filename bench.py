@@ -177,7 +177,7 @@ def main():
             model.prefetch(xyz)  # sampling pyramid of the next batch, concurrent with this backward
         loss.backward()
         bucket.reduce()
-        opt.step(bucket.flat if world > 1 else None)
+        opt.step(bucket.flat)
         return loss
 
     def infer_step():
@@ -225,7 +225,7 @@ def main():
                     static.draw()
                 fwd_bwd()
                 bucket.reduce()
-                opt.step(bucket.flat if world > 1 else None)
+                opt.step(bucket.flat)
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         bucket.zero()
@@ -242,7 +242,7 @@ def main():
                 static.draw()
             graph.replay()
             bucket.reduce()
-            opt.step(bucket.flat if world > 1 else None)
+            opt.step(bucket.flat)
             return loss_buf
 
         def eager_step():
@@ -253,7 +253,7 @@ def main():
             torch._foreach_zero_(grads)
             fwd_bwd()
             bucket.reduce()
-            opt.step(bucket.flat if world > 1 else None)
+            opt.step(bucket.flat)
             return loss_buf
 
         step = graph_step

@@ -10,7 +10,11 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller; outputs are pre-allocated; the
- *     library allocates nothing and keeps no state (re-entrant per stream)
+ *     library allocates no device memory.  Process-wide state is limited to two things, neither of
+ *     which decides which bytes a launch may touch: the concurrency hint (pcb_set_concurrency_hint,
+ *     an atomic int read once per call: it sizes grids, never buffers -- slab counts are explicit
+ *     arguments) and the roofline timer (pcb_timer_*, a mutex-guarded event list, off unless armed).
+ *     Calls on different streams are otherwise independent.
  *   - tensors are dense row-major with the shapes written next to each argument
  *   - indices are int64 at the boundary, as in the reference (torch.long)
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work
@@ -24,6 +28,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* Storage type of the activation rows of the shared-MLP engine: bf16 (8 columns per 16-byte chunk;
+ * BASELINE config 2) or fp32 (4 columns per chunk; the parity mode: logits within 1e-4 of the
+ * reference's fp32 Conv/BatchNorm).  Statistics, constants, parameters and their gradients are fp32
+ * in both. */
+typedef enum pcb_dtype { PCB_DTYPE_BF16 = 0, PCB_DTYPE_F32 = 1 } pcb_dtype;
 
 typedef enum pcb_status {
     PCB_OK = 0,
@@ -255,8 +265,16 @@ int pcb_edge_features_bwd(const float *grad_out, const int64_t *idx, int B, int 
  * gradients of the affine parameters are fp32.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).
  */
 
+/* Every entry point of this section exists for both row types: *_bf16 (C % 8 == 0, C <= 2048) and
+ * *_f32 (C % 4 == 0, C <= 1024) with the same arguments. */
+
 /* sums[0][c] += sum_r y[r][c]; sums[1][c] += sum_r y[r][c]^2.  sums [2,C] fp32, zeroed by the caller. */
 int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream);
+int pcb_colstats_f32(const void *y, long rows, int C, float *sums, void *stream);
+
+/* out[i] = sum over k < nparts of slabs[k][i], i < n, in slab order (fp64 accumulation).  The local
+ * totals of a [nparts][2][C] statistics buffer (n = 2C) -- what a SyncBatchNorm all-reduce carries. */
+int pcb_sum_slabs(const float *slabs, int nparts, int n, float *out, void *stream);
 
 /*
  * BatchNorm bookkeeping of one layer: scale = gamma*invstd, shift = beta - mean*scale.
@@ -282,6 +300,8 @@ int pcb_bn_finalize(const float *sums, int nparts, long rows, long count, int C,
 /* z = act(y*scale + shift), y/z [rows,C] bf16. */
 int pcb_bn_act_bf16(const void *y, const float *scale, const float *shift, long rows, int C, int act,
                     void *z, void *stream);
+int pcb_bn_act_f32(const void *y, const float *scale, const float *shift, long rows, int C, int act,
+                   void *z, void *stream);
 
 /*
  * Pooled form (torch.max over the neighbour axis, pointnet2_utils.py:154 / :356, DGCNN.py:136):
@@ -290,6 +310,8 @@ int pcb_bn_act_bf16(const void *y, const float *scale, const float *shift, long 
  */
 int pcb_bn_act_max_bf16(const void *y, const float *scale, const float *shift, long groups, int ns,
                         int C, int act, void *out, unsigned char *argmax, void *stream);
+int pcb_bn_act_max_f32(const void *y, const float *scale, const float *shift, long groups, int ns,
+                       int C, int act, void *out, unsigned char *argmax, void *stream);
 
 /*
  * Backward of act(BatchNorm(y)) for a dense upstream gradient dz [rows,C] bf16:
@@ -299,31 +321,45 @@ int pcb_bn_act_max_bf16(const void *y, const float *scale, const float *shift, l
 int pcb_bn_act_bwd_bf16(const void *dz, const void *y, const float *scale, const float *shift,
                         const float *mean, const float *invstd, long rows, int C, int act,
                         int use_batch_stats, float *sums, void *dy, void *stream);
+int pcb_bn_act_bwd_f32(const void *dz, const void *y, const float *scale, const float *shift,
+                       const float *mean, const float *invstd, long rows, int C, int act,
+                       int use_batch_stats, float *sums, void *dy, void *stream);
 
 /* Same for the pooled form: dout [groups,C] fp32 reaches only the arg-max rows; dy [groups*ns,C] bf16. */
 int pcb_bn_act_max_bwd_bf16(const float *dout, const unsigned char *argmax, const void *y,
                             const float *scale, const float *shift, const float *mean,
                             const float *invstd, long groups, int ns, int C, int act,
                             int use_batch_stats, float *sums, void *dy, void *stream);
+int pcb_bn_act_max_bwd_f32(const float *dout, const unsigned char *argmax, const void *y,
+                           const float *scale, const float *shift, const float *mean,
+                           const float *invstd, long groups, int ns, int C, int act,
+                           int use_batch_stats, float *sums, void *dy, void *stream);
 
 /*
- * Grouping straight into bf16 GEMM rows (sample_and_group / MSG grouping, pointnet2_utils.py:51-58,
+ * Grouping straight into GEMM rows (sample_and_group / MSG grouping, pointnet2_utils.py:51-58,
  * :342-349): out[(b,s,j)] = [feat[b,idx] (C) | xyz[b,idx]-new_xyz[b,s] (3) | 0 ... Kp).
  * Features come FIRST here (16-byte chunks stay aligned); the caller permutes the weight columns.
- * feat [B,N,C] bf16 or NULL, out [B*S*ns, Kp] bf16, Kp % 8 == 0, Kp >= C+3.
+ * feat [B,N,C] (row type) or NULL, out [B*S*ns, Kp], Kp % 8 == 0 (bf16) / Kp % 4 == 0 (fp32), Kp >= C+3.
  */
 int pcb_group_rows_bf16(const float *xyz, const float *new_xyz, const void *feat, const int64_t *idx,
                         int B, int N, int S, int ns, int C, int Kp, void *out, void *stream);
+int pcb_group_rows_f32(const float *xyz, const float *new_xyz, const void *feat, const int64_t *idx,
+                       int B, int N, int S, int ns, int C, int Kp, void *out, void *stream);
 
 /* grad_feat[b,idx,c] += grad_rows[row][c] (c < C); grad_feat [B,N,C] fp32 zeroed by the caller. */
 int pcb_group_rows_bf16_bwd(const void *grad_rows, const int64_t *idx, int B, int N, int S, int ns,
                             int C, int Kp, float *grad_feat, void *stream);
+int pcb_group_rows_f32_bwd(const void *grad_rows, const int64_t *idx, int B, int N, int S, int ns,
+                           int C, int Kp, float *grad_feat, void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * bf16 MFMA row GEMMs with the neighbouring BatchNorm/activation algebra fused into operand loads
- * and epilogues (csrc/gemm.hip).  Together with pcb_bn_finalize / pcb_bn_act_max_bf16 they are the
- * whole Conv(1x1) -> BatchNorm -> activation stack of models/pointnet2_utils.py:149-154, :207-209,
- * :353-356 and models/DGCNN.py:134-148: a layer stores only y = x W^T (bf16 rows).
+ * MFMA row GEMMs with the neighbouring BatchNorm/activation algebra fused into operand loads and
+ * epilogues (csrc/gemm.hip: bf16 rows on v_mfma_f32_32x32x16_bf16; csrc/gemm_f32.hip: fp32 rows on
+ * the exact fp32 matrix core v_mfma_f32_32x32x2_f32).  Together with pcb_bn_finalize /
+ * pcb_bn_act_max_* they are the whole Conv(1x1) -> BatchNorm -> activation stack of
+ * models/pointnet2_utils.py:149-154, :207-209, :353-356 and models/DGCNN.py:134-148: a layer stores
+ * only y = x W^T.  Every entry point exists as *_bf16 (N, K multiples of 8) and *_f32 (multiples of
+ * 4) with the same arguments; in the fp32 mode no library GEMM and no ATen BatchNorm runs.
  *
  * A-operand prologue `pro`:
  *   0  plain rows a0 [R,K]
@@ -331,16 +367,25 @@ int pcb_group_rows_bf16_bwd(const void *grad_rows, const int64_t *idx, int B, in
  *   2  dy = scale*dz*act'(y*scale+shift) + p*y + q    with dz = a0, y = a1 (BatchNorm backward)
  *   3  the same with dz[r][c] = (r % ns == argmax[r/ns][c]) ? dout[r/ns][c] : 0  (max-pooled layer)
  * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  scale/shift/p/q are fp32 [K].
+ *
+ * Statistics slabs: a launch given `sums` runs EXACTLY `nparts` workgroups along its row axis
+ * (1 <= nparts <= 768) and workgroup i stores the column sums / sums of squares of the outputs it
+ * produced into slab i of sums = [nparts][2][N] fp32 (no atomics; pcb_bn_finalize adds the slabs in
+ * order; a workgroup without rows stores zeros).  The count is the caller's: it sized the buffer for
+ * it and passes the same number to the finalize call.  pcb_gemm_nt_partials(pro,R,N) is the count
+ * the library would pick itself (resident workgroups for the concurrency hint in force) -- a
+ * recommendation, not a contract.
  */
 
-/* out[R,N] (bf16) = A'[R,K] . w[N,K]^T, fp32 accumulation.  If sums != NULL it is a
- * [pcb_gemm_nt_partials(pro,R,N)][2][N] fp32 buffer: every workgroup stores the column sums / sums of
- * squares of the rounded outputs it produced into its own slab (no atomics; pcb_bn_finalize adds
- * the slabs).  N % 8 == 0, K % 8 == 0. */
+/* out[R,N] = A'[R,K] . w[N,K]^T, fp32 accumulation.  sums/nparts: see above (NULL/0: no statistics). */
 int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale, const float *shift,
                      const float *p, const float *q, const float *dout, const unsigned char *argmax,
-                     int ns, int act, const void *w, long R, int N, int K, void *out, float *sums,
+                     int ns, int act, const void *w, long R, int N, int K, void *out, float *sums, int nparts,
                      void *stream);
+int pcb_gemm_nt_f32(int pro, const void *a0, const void *a1, const float *scale, const float *shift,
+                    const float *p, const float *q, const float *dout, const unsigned char *argmax,
+                    int ns, int act, const void *w, long R, int N, int K, void *out, float *sums, int nparts,
+                    void *stream);
 
 /* out[R,N] fp32 = a[R,K] (bf16) . w[N,K]^T (bf16): the plain GEMM with an UNROUNDED result, for the
  * per-point products of csrc/gatherlin.hip (replaces torch.matmul on R = B*N rows). */
@@ -349,43 +394,56 @@ int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int N, int K, 
 /*
  * Conv without BatchNorm (the second conv of EnhancedFeaturePropagation.attention / .boundary_aware,
  * models/pointnet2_utils.py:232-236, :279-283, and the classifier conv of the heads, models/model.py:98,
- * models/pointnet2.py:33): out [R,N] bf16 = a [R,K] . w [N,K]^T + bias [N] (fp32, may be NULL), the bias
- * added to the fp32 accumulators.  N % 8 == 0, K % 8 == 0.
- * pcb_prep_linear_bias_bf16 builds its operands in one launch from the fp32 parameters: w [n,k] ->
- * wp [npad,kp] and (optional) wt [kp,npad] bf16, zero padded; bias [n] (or NULL) -> bp [npad] fp32.
+ * models/pointnet2.py:33): out [R,N] = a [R,K] . w [N,K]^T + bias [N] (fp32, may be NULL), the bias
+ * added to the fp32 accumulators.
+ * pcb_prep_linear_bias_* builds its operands in one launch from the fp32 parameters: w [n,k] ->
+ * wp [npad,kp] and (optional) wt [kp,npad] in the row type, zero padded; bias [n] (or NULL) -> bp [npad] fp32.
  * gap = D > 0: the n outputs are laid out like interpolate+concat rows (first D in place, the others
- * from column pad8(D)), so the result can gate / join such rows without a permutation.
+ * from column pad(D), the next multiple of 8 (bf16) / 4 (fp32)), so the result can gate / join such
+ * rows without a permutation.
  */
 int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *bias, long R, int N, int K, void *out,
                           void *stream);
+int pcb_gemm_nt_bias_f32(const void *a, const void *w, const float *bias, long R, int N, int K, void *out,
+                         void *stream);
 int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
                               void *wp, void *wt, float *bp, void *stream);
+int pcb_prep_linear_bias_f32(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
+                             void *wp, void *wt, float *bp, void *stream);
 
 /* Tell the library that another kernel occupies about `busy_cus` compute units beside the launches
  * that follow (e.g. the next batch's FPS on a side stream during the backward pass): the persistent
- * input-gradient GEMMs then size their grids for the remaining CUs.  0 = the GPU is ours (default).
- * Query pcb_gemm_nt_partials AFTER setting the hint: the slab count follows the grid. */
+ * GEMMs without slabs, the weight-gradient splits and the slab-count recommendation then leave
+ * those CUs alone.  0 = the GPU is ours (default).  An atomic hint: it never changes which buffers a
+ * launch may touch. */
 int pcb_set_concurrency_hint(int busy_cus);
 
-/* Number of per-workgroup statistics slabs pcb_gemm_nt_bf16 writes for these sizes (never more than 768). */
+/* Recommended slab count (= workgroups along the row axis) for a gemm_nt launch of these sizes under
+ * the current hint; never more than 768. */
 int pcb_gemm_nt_partials(int pro, long R, int N);
 
 /* dW[M,N] (fp32, overwritten) = A'[R,M]^T . B'[R,N].
  * A' = dz [R,M] itself (apro 0) or dy (apro 2 or 3, as above, built from dz|dout+argmax and y [R,M]);
- * B' = x [R,N] (bpro 0) or act(x*xscale + xshift) (bpro 1).  M % 8 == 0, N % 8 == 0.
+ * B' = x [R,N] (bpro 0) or act(x*xscale + xshift) (bpro 1).
  * The rows are split over workgroups; each split stores its partial tile into `workspace`
  * (pcb_gemm_tn_workspace(R,M,N) floats, caller-owned) and a second kernel sums the slabs in a fixed
  * order, so the result is bitwise reproducible (no atomics).
  * Output layout: out_cols <= 0 gives dW [M, N].  out_cols = k > 0 gives dW [M, k] in the layer's
  * REAL weight layout, dropping the padding of the row layout out_perm describes (perm of
- * pcb_prep_weights_bf16) -- the gradient then needs no unpadding pass. */
+ * pcb_prep_weights_*) -- the gradient then needs no unpadding pass. */
 int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const float *scale, const float *shift,
                      const float *p, const float *q, const float *dout, const unsigned char *argmax,
                      int ns, int act, int bpro, const void *x, const float *xscale, const float *xshift,
                      int xact, long R, int M, int N, float *workspace, float *dW, int out_cols,
                      int out_perm, void *stream);
+int pcb_gemm_tn_f32(int apro, const void *dz, const void *y, const float *scale, const float *shift,
+                    const float *p, const float *q, const float *dout, const unsigned char *argmax,
+                    int ns, int act, int bpro, const void *x, const float *xscale, const float *xshift,
+                    int xact, long R, int M, int N, float *workspace, float *dW, int out_cols,
+                    int out_perm, void *stream);
 
-/* Number of fp32 elements pcb_gemm_tn_bf16 needs in `workspace` for these sizes. */
+/* Number of fp32 elements pcb_gemm_tn_* needs in `workspace` for these sizes (an upper bound for
+ * every value of the concurrency hint). */
 long pcb_gemm_tn_workspace(long R, int M, int N);
 
 /* p, q of the fused BatchNorm backward from sums = [nparts][2][C] partial slabs of
@@ -393,58 +451,78 @@ long pcb_gemm_tn_workspace(long R, int M, int N);
  * use_batch_stats == 0.  The parameter gradients the totals amount to are written to dgamma (= s2),
  * dbeta (= s1) and dbias (0 under batch statistics, scale*s1 otherwise), [C] each, any may be NULL.
  * With nparts == 1 (a slab the reduce kernels accumulated into with atomics) the slab is cleared
- * after use, ready for the next accumulation. */
+ * after use, ready for the next accumulation.
+ * global_sums (optional, [2][C]): the same two sums over the rows of ALL ranks (SyncBatchNorm; `rows`
+ * then counts all ranks' rows): p and q come from them, the parameter gradients stay local. */
 int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *scale,
                         const float *mean, const float *invstd, int use_batch_stats, float *p, float *q,
-                        float *dgamma, float *dbeta, float *dbias, void *stream);
+                        float *dgamma, float *dbeta, float *dbias, const float *global_sums, void *stream);
 
-/* bf16 GEMM operands of n <= 8 layers from their fp32 master weights, in one launch
+/* GEMM operands of n <= 8 layers from their fp32 master weights, in one launch
  * (replaces weight.view(Cout,Cin).to(bf16) / F.pad / .t().contiguous() per layer).
- * desc = n x 8 int64 on the HOST: {w fp32 [C,k], wp bf16 [C,kp], wt bf16 [kp,C] or 0, C, k, kp, perm, 0}.
+ * desc = n x 8 int64 on the HOST: {w fp32 [C,k], wp [C,kp], wt [kp,C] or 0, C, k, kp, perm, 0}; wp, wt
+ * in the row type of the entry point.
  * perm names the column layout of the layer's input rows: 0 = real columns in place, zero padded;
- * C > 0 = pcb_group_rows_bf16 rows (C feature columns, then the 3 centred coordinates);
- * -D < 0 = interpolate+concat rows (first D columns in place, the rest from column pad8(D)). */
+ * C > 0 = pcb_group_rows_* rows (C feature columns, then the 3 centred coordinates);
+ * -D < 0 = interpolate+concat rows (first D columns in place, the rest from column pad(D)). */
 int pcb_prep_weights_bf16(int n, const long long *desc, void *stream);
+int pcb_prep_weights_f32(int n, const long long *desc, void *stream);
 /* The same, and `zero` [zero_n] fp32 is cleared by the same launch (a stack's constants buffer). */
 int pcb_prep_weights_zero_bf16(int n, const long long *desc, float *zero, long zero_n, void *stream);
+int pcb_prep_weights_zero_f32(int n, const long long *desc, float *zero, long zero_n, void *stream);
 
-/* pcb_gemm_nt_bf16 (pro 2 or 3, N <= 128) whose epilogue also accumulates the BatchNorm-backward
- * sums of the layer BELOW: the produced tile is that layer's dz; with its y (red_y [R,N] bf16) and
- * constants, (sum du, sum du*xhat) go to red_sums = [pcb_gemm_nt_partials(pro,R,N)][2][N] slabs.
- * Saves the separate pcb_bn_act_bwd_reduce_bf16 pass over (dz, y). */
+/* pcb_gemm_nt_* (pro 2 or 3, N <= 128) whose epilogue also accumulates the BatchNorm-backward
+ * sums of the layer BELOW: the produced tile is that layer's dz; with its y (red_y [R,N]) and
+ * constants, (sum du, sum du*xhat) go to red_sums = [nparts][2][N] slabs (nparts as above).
+ * Saves the separate pcb_bn_act_bwd_reduce_* pass over (dz, y). */
 int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, const float *scale, const float *shift,
                          const float *p, const float *q, const float *dout, const unsigned char *argmax,
                          int ns, int act, const void *w, long R, int N, int K, void *out, const void *red_y,
                          const float *red_scale, const float *red_shift, const float *red_mean,
-                         const float *red_invstd, int red_act, float *red_sums, void *stream);
+                         const float *red_invstd, int red_act, float *red_sums, int nparts, void *stream);
+int pcb_gemm_nt_red_f32(int pro, const void *a0, const void *a1, const float *scale, const float *shift,
+                        const float *p, const float *q, const float *dout, const unsigned char *argmax,
+                        int ns, int act, const void *w, long R, int N, int K, void *out, const void *red_y,
+                        const float *red_scale, const float *red_shift, const float *red_mean,
+                        const float *red_invstd, int red_act, float *red_sums, int nparts, void *stream);
 
 /* Backward sums only (no dy written): sums += (sum du, sum du*xhat) for a dense dz ... */
 int pcb_bn_act_bwd_reduce_bf16(const void *dz, const void *y, const float *scale, const float *shift,
                                const float *mean, const float *invstd, long rows, int C, int act,
                                float *sums, void *stream);
+int pcb_bn_act_bwd_reduce_f32(const void *dz, const void *y, const float *scale, const float *shift,
+                              const float *mean, const float *invstd, long rows, int C, int act,
+                              float *sums, void *stream);
 
 /* ... and for a max-pooled layer (dout [groups,C] fp32, argmax [groups,C] uint8). */
 int pcb_bn_act_max_bwd_reduce_bf16(const float *dout, const unsigned char *argmax, const void *y,
                                    const float *scale, const float *shift, const float *mean,
                                    const float *invstd, long groups, int ns, int C, int act, float *sums,
                                    void *stream);
+int pcb_bn_act_max_bwd_reduce_f32(const float *dout, const unsigned char *argmax, const void *y,
+                                  const float *scale, const float *shift, const float *mean,
+                                  const float *invstd, long groups, int ns, int C, int act, float *sums,
+                                  void *stream);
 
 /*
- * bf16 interpolation written straight into the row buffer of the following GEMM
+ * Interpolation written straight into the row buffer of the following GEMM
  * (FeaturePropagation.forward, models/pointnet2_utils.py:191-203: interpolate + concatenate):
  * out[(b,n)][col0 .. col0+C) = sum_k w_k * feat[b, idx[b,n,k], :], w as in pcb_interpolate.
- * feat [B,S,C] bf16, out [B*N, ld] bf16, C/ld/col0 multiples of 8, out_w [B,N,k] fp32 (optional).
+ * feat [B,S,C], out [B*N, ld] in the row type; C/ld/col0 multiples of 8 (bf16) / 4 (fp32);
+ * out_w [B,N,k] fp32 (optional).  The fp32 form rounds like pcb_interpolate (product, then sum).
  */
 int pcb_interpolate_bf16(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C,
                          int k, void *out, int ld, int col0, float *out_w, void *stream);
+int pcb_interpolate_rows_f32(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C,
+                             int k, void *out, int ld, int col0, float *out_w, void *stream);
 
 /*
  * Backward of the interpolation without atomics: an inverted index of the (n,q) pairs by target
  * s (counting sort: pcb_interp_csr_count -> prefix sum by the caller -> pcb_interp_csr_fill), then
- * one wave per target sums its contribution rows (pcb_interpolate_bwd_csr_bf16).
+ * one wave per target sums its contribution rows (pcb_interpolate_bwd_csr_*).
  *   count/cursor [B*S] int32 zeroed by the caller; offsets [B*S+1] int64 = exclusive prefix sum of
- *   count; entries [B*N*k] int32; grad_rows [B*N, ld] bf16 (columns col0..col0+C); w [B,N,k] fp32;
- *   grad_feat [B,S,C] bf16 (overwritten).
+ *   count; entries [B*N*k] int32; grad_rows [B*N, ld] (columns col0..col0+C); w [B,N,k] fp32;
+ *   grad_feat [B,S,C] (overwritten), both in the row type.
  */
 int pcb_interp_csr_count(const int64_t *idx, int B, int N, int S, int k, int *count, void *stream);
 int pcb_interp_csr_fill(const int64_t *idx, int B, int N, int S, int k, const long *offsets, int *cursor,
@@ -452,12 +530,17 @@ int pcb_interp_csr_fill(const int64_t *idx, int B, int N, int S, int k, const lo
 int pcb_interpolate_bwd_csr_bf16(const void *grad_rows, int ld, int col0, const float *w, const long *offsets,
                                  const int *entries, int B, int N, int S, int C, int k, void *grad_feat,
                                  void *stream);
+int pcb_interpolate_bwd_csr_f32(const void *grad_rows, int ld, int col0, const float *w, const long *offsets,
+                                const int *entries, int B, int N, int S, int C, int k, void *grad_feat,
+                                void *stream);
 
 /* Channel-attention gate of EnhancedFeaturePropagation (models/pointnet2_utils.py:279-280):
- * out = x * sigmoid(a) on n bf16 elements (n % 8 == 0), one pass; backward dx = g*sigmoid(a),
- * da = g*x*s*(1-s), one pass. */
+ * out = x * sigmoid(a) on n row elements (n % 8 == 0 bf16, n % 4 == 0 fp32), one pass; backward
+ * dx = g*sigmoid(a), da = g*x*s*(1-s), one pass. */
 int pcb_gate_bf16(const void *x, const void *a, void *out, long n, void *stream);
+int pcb_gate_f32(const void *x, const void *a, void *out, long n, void *stream);
 int pcb_gate_bwd_bf16(const void *g, const void *x, const void *a, void *dx, void *da, long n, void *stream);
+int pcb_gate_bwd_f32(const void *g, const void *x, const void *a, void *dx, void *da, long n, void *stream);
 
 /*
  * A whole stack of L <= PCB_STACK_MAX_LAYERS shared-MLP layers  x -> act(BN(x W^T + b))  [-> max over
@@ -465,42 +548,57 @@ int pcb_gate_bwd_bf16(const void *g, const void *x, const void *a, void *dx, voi
  *   for i, conv in enumerate(self.mlp_convs): new_points = F.relu(self.mlp_bns[i](conv(new_points)))
  *   new_points = torch.max(new_points, 2)[0]
  * (models/pointnet2_utils.py:149-154, :207-209, :353-356; models/DGCNN.py:134-148).  The calls are
- * exactly the sequence of pcb_prep_weights_bf16 / pcb_gemm_nt_bf16 / pcb_bn_finalize /
- * pcb_bn_act(_max)_bf16 (forward) and pcb_bn_act(_max)_bwd_reduce_bf16 / pcb_bn_bwd_finalize /
- * pcb_gemm_tn_bf16 / pcb_gemm_nt(_red)_bf16 (backward) a caller would issue itself; issuing them
+ * exactly the sequence of pcb_prep_weights_* / pcb_gemm_nt_* / pcb_bn_finalize /
+ * pcb_bn_act(_max)_* (forward) and pcb_bn_act(_max)_bwd_reduce_* / pcb_bn_bwd_finalize /
+ * pcb_gemm_tn_* / pcb_gemm_nt(_red)_* (backward) a caller would issue itself; issuing them
  * from native code keeps the host ahead of the GPU (one foreign call per stack and direction).
+ * dtype selects the row type (pcb_dtype) of x, y, out, g, dx, dzbuf and wbuf; the sequence is the same.
  *
  * desc: L x 16 int64 on the HOST, per layer
  *   [0] w fp32 [C,k]  [1] conv bias [C] or 0  [2] gamma or 0  [3] beta or 0
- *   [4] running_mean or 0  [5] running_var or 0  [6] C (multiple of 8)  [7] k = real input columns
+ *   [4] running_mean or 0  [5] running_var or 0  [6] C (multiple of 8 / 4)  [7] k = real input columns
  *   [8] 1: batch statistics (training), 0: running statistics
- *   [9] y bf16 [R,C]: the layer's pre-BatchNorm GEMM output (written by forward, read by backward)
+ *   [9] y [R,C]: the layer's pre-BatchNorm GEMM output (written by forward, read by backward)
  *   [10] dW fp32 [C,k]  [11] dgamma [C]  [12] dbeta [C]  [13] dbias [C]   (backward outputs, any may be 0)
  *   [14] num_batches_tracked (int64 scalar, forward: += 1) or 0
  * fdesc: L x 2 doubles: momentum, eps.  stat_repeat >= 1: every row of x stands for that many
  * identical samples (see pcb_bn_finalize `count`); 1 otherwise.
- * x bf16 [R,Kp] rows in the column layout `perm` (see pcb_prep_weights_bf16); act 0/1/2;
- * pool = 0 (out bf16 [R,C_last]) or ns (out bf16 [R/ns,C_last] + argmax uint8).
+ * x [R,Kp] rows in the column layout `perm` (see pcb_prep_weights_*); act 0/1/2;
+ * pool = 0 (out [R,C_last]) or ns (out [R/ns,C_last] + argmax uint8).
  * Caller-owned scratch shared by forward and backward of the same stack:
- *   wbuf  bf16, pcb_mlp_stack_wbuf_elems(L,desc,Kp,need_wt0) elements (prepared weights; need_wt0 = the
+ *   wbuf  row type, pcb_mlp_stack_wbuf_elems(L,desc,Kp,need_wt0) elements (prepared weights; need_wt0 = the
  *         input gradient dx will be wanted);   stz fp32 [10 * sum C] (per-layer constants);
- *   parts fp32, >= 2 * C * pcb_gemm_nt_partials(pro,R,C) for every layer (statistics slabs).
+ *   parts fp32 [parts_slabs][2][max C]: statistics slabs.  No launch of the call writes more than
+ *         parts_slabs slabs, whatever the concurrency hint says (a gathered first layer uses up to 1024,
+ *         the GEMMs up to 768; fewer slabs only mean fewer resident workgroups).
+ * sync (optional): SyncBatchNorm.  After each training-mode layer's statistics the local totals
+ *   [2][C] are handed to sync->allreduce(buf, n, ctx) -- called on the host, between launches; it must
+ *   enqueue a SUM all-reduce of the n floats at device pointer buf in stream order (return 0) -- and
+ *   the layer is normalised with the statistics of sync->global_rows rows (all ranks' R).  Backward:
+ *   the two BatchNorm-backward sums travel the same way; parameter gradients stay local.
  * Forward, need_wt0 bit 1 (value 2): every layer is in eval mode and wbuf / stz still hold what an
  * earlier call with the same, unchanged parameters and running statistics left there -- operand
  * preparation and the per-layer BatchNorm finalize are skipped (inference with constant weights).
- * Backward only: g = dz bf16 [R,C_last] (pool 0) or dout fp32 [R/ns,C_last]; workspace fp32, >= the
+ * Backward only: g = dz [R,C_last] (pool 0) or dout fp32 [R/ns,C_last]; workspace fp32, >= the
  * SUM of pcb_gemm_tn_workspace(R,C_l,Kp_l) over the layers that have a dW (each keeps its slabs until
- * one launch at the end of the pass sums them all); dzbuf bf16 [2][R][max width] (L > 1); dx bf16 [R,Kp] or NULL.
+ * one launch at the end of the pass sums them all); dzbuf [2][R][max width] (L > 1); dx [R,Kp] or NULL.
  */
 #define PCB_STACK_MAX_LAYERS 16
+typedef struct pcb_sync {
+    int (*allreduce)(float *buf, int n, void *ctx);
+    void *ctx;
+    long global_rows;
+} pcb_sync;
 long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, int need_wt0);
-int pcb_mlp_stack_forward(int L, const long long *desc, const double *fdesc, const void *x, long R, int Kp,
-                          int perm, int act, int pool, int need_wt0, int stat_repeat, const long long *gather,
-                          void *wbuf, float *stz, float *parts, void *out, unsigned char *argmax, void *stream);
-int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const void *g,
+int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, const double *fdesc, const void *x, long R,
+                          int Kp, int perm, int act, int pool, int need_wt0, int stat_repeat,
+                          const long long *gather, void *wbuf, float *stz, float *parts, int parts_slabs,
+                          const pcb_sync *sync, void *out, unsigned char *argmax, void *stream);
+int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, const void *x, const void *g,
                            const unsigned char *argmax, long R, int Kp, int perm, int act, int pool,
                            int need_wt0, const long long *gather, const void *wbuf, float *stz, float *parts,
-                           float *workspace, void *dzbuf, void *dx, void *stream);
+                           int parts_slabs, const pcb_sync *sync, float *workspace, void *dzbuf, void *dx,
+                           void *stream);
 
 /*
  * First layer of a GROUPED stack evaluated per point and gathered (csrc/gatherlin.hip): a 1x1
@@ -509,7 +607,8 @@ int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const vo
  * per-point products u (N rows per scene) and v (S rows per scene), both fp32 [.,C].
  *   pcb_gather_add_bf16   y[r,:] = bf16(u[b*N + idx[r],:] + v[r/ns,:] + Wx (xyz[b*N + idx[r]] - ctr[r/ns])),
  *                         r over B*S*ns rows, and the column sums / sums of squares of y into
- *                         [pcb_gather_add_partials(R,C)][2][C] slabs for pcb_bn_finalize.  v may be
+ *                         [nparts][2][C] slabs for pcb_bn_finalize: the launch runs exactly nparts
+ *                         workgroups (1..1024; pcb_gather_add_partials(R,C) is the recommendation).  v may be
  *                         NULL; the coordinate term (the reference's fp32 difference x_j - c_s times
  *                         the first 3 weight columns, wx [C,3] with row stride ldw) is used when wx
  *                         is not NULL (xyz [B,N,3], ctr [B,S,3] fp32).
@@ -529,7 +628,7 @@ int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const vo
 int pcb_gather_add_partials(long R, int C);
 int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S, int ns, int C,
                         const float *xyz, const float *ctr, const float *wx, int ldw, void *y, float *sums,
-                        void *stream);
+                        int nparts, void *stream);
 int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *scale, const float *shift,
                         const float *p, const float *q, const float *dout, const unsigned char *argmax, int act,
                         const int64_t *idx, int B, int N, int S, int ns, int C, const float *xyz,

@@ -41,42 +41,63 @@ SIGNATURES = {
     "pcb_edge_features": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_edge_features_bwd": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_colstats_bf16": [_p, _l, _i, _p, _p],
+    "pcb_colstats_f32": [_p, _l, _i, _p, _p],
+    "pcb_sum_slabs": [_p, _i, _i, _p, _p],
     "pcb_bn_finalize": [_p, _i, _l, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p],
     "pcb_set_concurrency_hint": [_i],
     "pcb_gemm_nt_partials": [_i, _l, _i],
     "pcb_gemm_nt_bias_bf16": [_p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_gemm_nt_bias_f32": [_p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_prep_linear_bias_bf16": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "pcb_prep_linear_bias_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "pcb_gemm_nt_f32out_bf16": [_p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_bf16": [_p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_bn_act_f32": [_p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_max_bf16": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
+    "pcb_bn_act_max_f32": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
     "pcb_bn_act_bwd_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
+    "pcb_bn_act_bwd_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
     "pcb_bn_act_max_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_bn_act_max_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
     "pcb_group_rows_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_group_rows_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "pcb_group_rows_bf16_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_group_rows_f32_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "pcb_interpolate_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
+    "pcb_interpolate_rows_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "pcb_interp_csr_count": [_p, _i, _i, _i, _i, _p, _p],
     "pcb_interp_csr_fill": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
     "pcb_interpolate_bwd_csr_bf16": [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
-    "pcb_gemm_nt_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p],
+    "pcb_interpolate_bwd_csr_f32": [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "pcb_gemm_nt_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _i, _p],
+    "pcb_gemm_nt_f32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _i, _p],
     "pcb_gemm_tn_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _i, _i, _p],
+    "pcb_gemm_tn_f32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _i, _i, _p],
     "pcb_gemm_tn_workspace": [_l, _i, _i],
-    "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "pcb_prep_weights_bf16": [_i, _p, _p],
+    "pcb_prep_weights_f32": [_i, _p, _p],
     "pcb_prep_weights_zero_bf16": [_i, _p, _p, _l, _p],
+    "pcb_prep_weights_zero_f32": [_i, _p, _p, _l, _p],
     "pcb_mlp_stack_wbuf_elems": [_i, _p, _i, _i],
-    "pcb_mlp_stack_forward": [_i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
-    "pcb_mlp_stack_backward": [_i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "pcb_mlp_stack_forward": [_i, _i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
+    "pcb_mlp_stack_backward": [_i, _i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
     "pcb_gather_add_partials": [_l, _i],
-    "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p],
+    "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p],
     "pcb_scatter_dy_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "pcb_gate_bf16": [_p, _p, _p, _l, _p],
+    "pcb_gate_f32": [_p, _p, _p, _l, _p],
     "pcb_gate_bwd_bf16": [_p, _p, _p, _p, _p, _l, _p],
+    "pcb_gate_bwd_f32": [_p, _p, _p, _p, _p, _l, _p],
     "pcb_timer_start": [],
     "pcb_timer_enable": [_i],
     "pcb_timer_stop": [_p, _p, _p],
-    "pcb_gemm_nt_red_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "pcb_gemm_nt_red_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p],
+    "pcb_gemm_nt_red_f32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     "pcb_bn_act_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_bn_act_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
+    "pcb_bn_act_max_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
 }
 
 _lib = None

@@ -232,13 +232,14 @@ extern "C" int pcb_gather_add_partials(long R, int C)
 
 extern "C" int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S,
                                    int ns, int C, const float *xyz, const float *ctr, const float *wx, int ldw,
-                                   void *y, float *sums, void *stream)
+                                   void *y, float *sums, int nparts, void *stream)
 {
     if (!u || !idx || !y || !sums || B <= 0 || N <= 0 || S <= 0 || ns <= 0) return PCB_ERR_INVALID_ARG;
+    if (nparts < 1 || nparts > 1024) return PCB_ERR_INVALID_ARG;  // the caller's slab count IS the grid
     if (wx && (!xyz || !ctr || ldw < 3)) return PCB_ERR_INVALID_ARG;
     if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
     const long R = (long)B * S * ns;
-    hipLaunchKernelGGL(gather_add_kernel, dim3((unsigned)gather_add_grid(R, C)), dim3(kThreads), 0,
+    hipLaunchKernelGGL(gather_add_kernel, dim3((unsigned)nparts), dim3(kThreads), 0,
                        (hipStream_t)stream, u, v, idx, N, S, ns, C, R, (u16 *)y, sums, xyz, ctr, wx, ldw);
     return pcb_check_launch();
 }

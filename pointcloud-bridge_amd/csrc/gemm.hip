@@ -13,7 +13,8 @@
 //          | dy(dout, argmax, y)                 the same for a max-pooled layer
 //       epilogue: bf16 store; optionally per-column sum / sum of squares (next BatchNorm's
 //       batch statistics) accumulated from the rounded outputs
-//   gemm_tn  dW[M,N] += A'[R,M]^T . B'[R,N]        (weight gradient, reduction over rows, fp32 atomics)
+//   gemm_tn  dW[M,N]  = A'[R,M]^T . B'[R,N]        (weight gradient; rows split over workgroups, per-split
+//                                                  slabs summed in a fixed order -- no atomics)
 //       A' = dy(...) as above, B' = plain rows | act(B*scale + shift)
 //
 // dy = scale*du + p*y + q with du = dz*act'(y*scale+shift); p, q fold the batch-statistics terms
@@ -26,7 +27,7 @@
 // loaded and read back with ds_read_b64_tr_b16 (hardware transpose read).
 #include <stdlib.h>
 
-#include "pcb_common.h"
+#include "gemm_shared.h"
 
 namespace {
 
@@ -219,7 +220,14 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
     // stream of stages and the next stage's loads are always in flight under the current MFMAs,
     // across tile boundaries too.
     long tile = blockIdx.x;
-    if (tile >= tiles_m) return;
+    if (tile >= tiles_m) {
+        // more slabs than row tiles: this workgroup has no rows, its slab must still read as zero
+        if ((STATS || RED) && t < NT_BN && n0 + t < N) {
+            sums[((long)blockIdx.x * 2 + 0) * N + n0 + t] = 0.0f;
+            sums[((long)blockIdx.x * 2 + 1) * N + n0 + t] = 0.0f;
+        }
+        return;
+    }
 
     f32x16 acc[4];
     // statistics: each lane owns one output column per 32-wide tile for the whole kernel, so the
@@ -678,185 +686,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
         }
 }
 
-// Column layouts of a padded GEMM operand [.., kp] against the layer's real weight [.., k]
-// (host side: rowmlp.padded_weight_from).  Returns the real column a padded column j holds, or -1
-// for padding.
-//   perm = 0      real columns in place, zero padded on the right
-//   perm = C > 0  grouped rows (pcb_group_rows_bf16): the C feature columns first, then the 3
-//                 centred coordinates (real order: coordinates first)
-//   perm = -D < 0 interpolate+concat rows: the first D columns in place, the rest from pad8(D)
-__device__ __forceinline__ int real_column(int j, int k, int perm)
-{
-    if (perm > 0) return j < perm ? 3 + j : (j < perm + 3 ? j - perm : -1);
-    if (perm < 0) {
-        const int d = -perm, dp = (d + 7) & ~7;
-        if (j < d) return j;
-        const int r = d + (j - dp);
-        return (j >= dp && r < k) ? r : -1;
-    }
-    return j < k ? j : -1;
-}
-
-// dW = sum over splits of part[s], in a fixed order (bitwise reproducible weight gradient), written
-// in the real weight layout [M, k] (padding columns dropped, see real_column).
-// 64 consecutive elements x 16 split-lanes per workgroup: coalesced slab reads, LDS tree at the end.
-__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restrict__ part, int splits,
-                                                             long elems, float *__restrict__ dW, int N, int k,
-                                                             int perm)
-{
-    __shared__ float red[16][64];
-    const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
-    for (long e0 = (long)blockIdx.x * 64; e0 < elems; e0 += (long)gridDim.x * 64) {
-        const long e = e0 + ex;
-        float a = 0.0f;
-        if (e < elems)
-            for (int s = sy; s < splits; s += 16) a += part[(long)s * elems + e];
-        red[sy][ex] = a;
-        __syncthreads();
-        if (sy == 0 && e < elems) {
-            float t = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) t += red[i][ex];
-            const long m = e / N;
-            const int r = real_column((int)(e - m * N), k, perm);
-            if (r >= 0) dW[m * k + r] = t;
-        }
-        __syncthreads();
-    }
-}
-
-// The same sum for up to kMaxPending weight gradients in ONE launch (blockIdx.y = entry): a stack's
-// backward pass parks the reductions of its layers (nothing in that pass reads dW) and runs them
-// together at its end instead of one 5-10 us launch behind every weight-gradient GEMM.
-constexpr int kMaxPending = 16;
-struct PendingReduce {
-    const float *part;
-    float *dW;
-    long elems;
-    int splits, N, k, perm;
-};
-struct ReduceBatch {
-    PendingReduce e[kMaxPending];
-};
-__global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch batch)
-{
-    __shared__ float red[16][64];
-    const PendingReduce r = batch.e[blockIdx.y];
-    const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
-    for (long e0 = (long)blockIdx.x * 64; e0 < r.elems; e0 += (long)gridDim.x * 64) {
-        const long e = e0 + ex;
-        float a = 0.0f;
-        if (e < r.elems)
-            for (int s = sy; s < r.splits; s += 16) a += r.part[(long)s * r.elems + e];
-        red[sy][ex] = a;
-        __syncthreads();
-        if (sy == 0 && e < r.elems) {
-            float t = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) t += red[i][ex];
-            const long m = e / r.N;
-            const int c = real_column((int)(e - m * r.N), r.k, r.perm);
-            if (c >= 0) r.dW[m * r.k + c] = t;
-        }
-        __syncthreads();
-    }
-}
-thread_local ReduceBatch g_pending;
-thread_local int g_npending = -1;  // < 0: every reduction runs right behind its GEMM (the default)
-
-// p, q of the fused BatchNorm backward of one layer from sums = [nparts][2][C] partial slabs of
-// (sum du, sum du*xhat); the parameter gradients the totals amount to go to dgamma, dbeta, dbias
-// ([C] each, optional): dbeta = s1, dgamma = s2, dbias = 0 under batch statistics (the mean
-// subtraction cancels a bias exactly), scale*s1 otherwise.
-// Block = 32 channels x 32 slab-lanes.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(float *__restrict__ sums, int nparts,
-                                                                long rows, int C, const float *__restrict__ scale,
-                                                                const float *__restrict__ mean,
-                                                                const float *__restrict__ invstd,
-                                                                int use_batch_stats, float *__restrict__ p,
-                                                                float *__restrict__ q, float *__restrict__ dgamma,
-                                                                float *__restrict__ dbeta, float *__restrict__ dbias)
-{
-    __shared__ float red[2][32][32];
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    float s1 = 0.0f, s2 = 0.0f;
-    if (c < C) {
-        for (int k = pl; k < nparts; k += 32) {
-            s1 += sums[((long)k * 2 + 0) * C + c];
-            s2 += sums[((long)k * 2 + 1) * C + c];
-        }
-    }
-    red[0][pl][cl] = s1;
-    red[1][pl][cl] = s2;
-    __syncthreads();
-    if (pl != 0 || c >= C) return;
-    s1 = 0.0f;
-    s2 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        s1 += red[0][k][cl];
-        s2 += red[1][k][cl];
-    }
-    if (nparts == 1) {
-        // a single slab was accumulated with atomics: leave it cleared for the next accumulation
-        sums[c] = 0.0f;
-        sums[C + c] = 0.0f;
-    }
-    if (dgamma) dgamma[c] = s2;
-    if (dbeta) dbeta[c] = s1;
-    if (dbias) dbias[c] = use_batch_stats ? 0.0f : scale[c] * s1;
-    if (!use_batch_stats) {
-        p[c] = 0.0f;
-        q[c] = 0.0f;
-        return;
-    }
-    const float invR = 1.0f / (float)rows;
-    const float a = s1 * invR;       // mean of du
-    const float b = s2 * invR;       // mean of du * xhat
-    const float sb = scale[c] * b * invstd[c];
-    p[c] = -sb;
-    q[c] = fmaf(sb, mean[c], -scale[c] * a);
-}
-
-// CUs to leave free while another kernel runs beside the backward pass (pcb_set_concurrency_hint).
-// Measured with the FPS kernel of the next batch on a side stream (16 workgroups): a 512-workgroup
-// persistent gemm_nt slows from 145 to 220 us, one of 448 runs in 163 us either way -- the persistent
-// grid assumes it owns every CU, and the workgroups that find their CU taken serialise behind others.
-long g_shared_cus = 0;
-
-// Workgroups along x of a gemm_nt launch (= slabs of its partials buffer): persistent over row
-// tiles, as many as are resident at once -- 3 per CU for the forward prologues, 2 for the
-// register-heavier backward ones (see the launch bounds of gemm_nt_kernel).
-// Tuning knobs for the persistent grids, clamped to [64, 768]: callers size their statistics slabs
-// for at most 768 workgroups (the documented upper bound of pcb_gemm_nt_partials); a larger grid
-// would write past them.
-long grid_knob(const char *name, long def)
-{
-    const char *e = getenv(name);
-    const long v = e ? atol(e) : def;
-    return v < 64 ? 64L : (v > 768 ? 768L : v);
-}
-
-long nt_grid_x(int pro, long R, int N)
-{
-    const long tiles = (R + NT_BM - 1) / NT_BM;
-    const long ny = (N + NT_BN - 1) / NT_BN;
-    static const long fwd_chip = grid_knob("PCB_NT_FWD_GRID", 768);
-    static const long bwd_chip = grid_knob("PCB_NT_BWD_GRID", 512);
-    // while another kernel holds CUs (pcb_set_concurrency_hint) the persistent grids leave them alone:
-    // 3 forward / 2 backward workgroups fit a CU
-    const long chip = pro <= PRO_BNACT ? fwd_chip - 3 * g_shared_cus : bwd_chip - 2 * g_shared_cus;
-    const long resident = chip / ny > 0 ? chip / ny : 1;
-    return tiles < resident ? tiles : resident;
-}
-
 template <int PRO>
-void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, float *sums, hipStream_t st,
+void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, float *sums, int nparts, hipStream_t st,
                const RedArgs *red = nullptr)
 {
+    // with slabs the caller's count IS the grid (it sized its buffer and its finalize call for it);
+    // without, the resident-workgroup preference for the hint in force now
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
-    const dim3 grid((unsigned)nt_grid_x(PRO, R, N), ny);
+    const dim3 grid((unsigned)(sums ? nparts : pcb_nt_grid_x(PRO, R, N, pcb_busy_cus())), ny);
     RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     if (red && PRO >= PRO_DY)
         hipLaunchKernelGGL((gemm_nt_kernel<PRO, 0, (PRO >= PRO_DY)>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums, *red);
@@ -866,43 +703,20 @@ void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, 
         hipLaunchKernelGGL((gemm_nt_kernel<PRO, 0, 0>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums, none);
 }
 
-// Row splits of the weight-gradient GEMM: enough workgroups to fill the chip (~1024), at least 8
-// stages of work each.  Returns the split count; *rows_per_split is a multiple of TN_RS.
-long tn_splits(long R, int M, int N, long *rows_per_split, long target = 512)
-{
-    const long tiles = (long)((M + TN_BM - 1) / TN_BM) * ((N + TN_BN - 1) / TN_BN);
-    long splits = (target + tiles - 1) / tiles;
-    const long max_splits = (R + 8 * TN_RS - 1) / (8 * TN_RS);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    long rps = (R + splits - 1) / splits;
-    rps = (rps + TN_RS - 1) / TN_RS * TN_RS;
-    *rows_per_split = rps;
-    return (R + rps - 1) / rps;
-}
-
 template <int APRO>
 void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int N, float *part, float *dW,
                int out_cols, int out_perm, hipStream_t st)
 {
     long rps;
     // fewer splits while another kernel holds CUs (never more than pcb_gemm_tn_workspace assumed)
-    const long splits = tn_splits(R, M, N, &rps, 512 - 2 * g_shared_cus);
+    const long splits = pcb_tn_splits(R, M, N, &rps, 512 - 2 * pcb_busy_cus());
     const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
     const dim3 grid((unsigned)(tm * tn * splits));
     if (bpro == PRO_PLAIN)
         hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, tm, tn);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, tm, tn);
-    const long elems = (long)M * N;
-    if (g_npending >= 0 && g_npending < kMaxPending && out_cols > 0) {
-        g_pending.e[g_npending++] = {part, dW, elems, (int)splits, N, out_cols, out_perm};
-        return;
-    }
-    long blocks = (elems + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, part, (int)splits, elems, dW, N,
-                       out_cols, out_perm);
+    (void)pcb_reduce_slabs(part, (int)splits, (long)M * N, dW, N, out_cols, out_perm, 8, st);
 }
 
 inline bool bad_dim(long v) { return v <= 0 || (v & 7) != 0; }
@@ -945,9 +759,10 @@ static Operand make_operand(const void *a0, const void *a1, long ld, const float
 extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const float *scale,
                                 const float *shift, const float *p, const float *q, const float *dout,
                                 const unsigned char *argmax, int ns, int act, const void *w, long R, int N,
-                                int K, void *out, float *sums, void *stream)
+                                int K, void *out, float *sums, int nparts, void *stream)
 {
     if (!w || !out || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (sums && (nparts < 1 || nparts > PCB_MAX_SLABS)) return PCB_ERR_INVALID_ARG;
     if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
     if (pro < 0 || pro > 3) return PCB_ERR_INVALID_ARG;
     if ((pro <= PRO_DY && !a0) || (pro >= PRO_DY && !a1) || (pro >= PRO_BNACT && (!scale || !shift))) return PCB_ERR_INVALID_ARG;
@@ -961,8 +776,7 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
     if (pro >= PRO_DY && !sums && N > NT_BN && K <= 256) {
         // wide input gradient: transformed A tile resident in LDS, column tiles walked inside
         const long tiles = (R + AR_BM - 1) / AR_BM;
-        static const long ares_base = grid_knob("PCB_NT_BWD_GRID", 512);
-        const long ares_chip = ares_base - 2 * g_shared_cus;
+        const long ares_chip = pcb_nt_grid_x(PRO_DY, (long)PCB_MAX_SLABS * NT_BM, NT_BN, pcb_busy_cus());  // the backward grid of a full chip
         const dim3 grid((unsigned)(tiles < ares_chip ? tiles : ares_chip));
         if (pro == PRO_DY) {
             if (K <= 128)
@@ -979,10 +793,10 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
         return pcb_check_launch();
     }
     switch (pro) {
-        case PRO_PLAIN: launch_nt<PRO_PLAIN>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
-        case PRO_BNACT: launch_nt<PRO_BNACT>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
-        case PRO_DY: launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
-        default: launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, st); break;
+        case PRO_PLAIN: launch_nt<PRO_PLAIN>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, nparts, st); break;
+        case PRO_BNACT: launch_nt<PRO_BNACT>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, nparts, st); break;
+        case PRO_DY: launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, nparts, st); break;
+        default: launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, nparts, st); break;
     }
     pcb_timer_end(st, timed, bytes, pro, R, N, K);
     return pcb_check_launch();
@@ -994,7 +808,7 @@ extern "C" int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int
     if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
     const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
-    const dim3 grid((unsigned)nt_grid_x(PRO_PLAIN, R, N), ny);
+    const dim3 grid((unsigned)pcb_nt_grid_x(PRO_PLAIN, R, N, pcb_busy_cus()), ny);
     const RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
@@ -1014,7 +828,7 @@ extern "C" int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *
     if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
     const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
-    const dim3 grid((unsigned)nt_grid_x(PRO_PLAIN, R, N), ny);
+    const dim3 grid((unsigned)pcb_nt_grid_x(PRO_PLAIN, R, N, pcb_busy_cus()), ny);
     const RedArgs epi = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, bias};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
@@ -1022,37 +836,6 @@ extern "C" int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *
     hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out,
                        (float *)nullptr, epi);
     pcb_timer_end(st, timed, nt_bytes(PRO_PLAIN, R, N, K, 0), PRO_PLAIN, R, N, K);
-    return pcb_check_launch();
-}
-
-// Operands of a bias-only conv in one launch: w [n,k] fp32 -> wp [npad,kp] and wt [kp,npad] bf16 (zero
-// padded), bias [n] -> bp [npad] fp32.  gap = D > 0: the n outputs use the interpolate+concat
-// column layout (first D in place, the rest from column pad8(D)), see real_column(.., -D).
-namespace {
-__global__ __launch_bounds__(256) void prep_linear_bias_kernel(const float *__restrict__ w, const float *__restrict__ bias,
-                                                               int n, int k, int npad, int kp, int gap,
-                                                               u16 *__restrict__ wp, u16 *__restrict__ wt,
-                                                               float *__restrict__ bp)
-{
-    const int total = npad * kp;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int o = e / kp, j = e - o * kp;
-        const int r = real_column(o, n, -gap);   // gap = 0: o < n ? o : -1
-        const u16 h = (r >= 0 && j < k) ? f2bf(w[(long)r * k + j]) : (u16)0;
-        wp[e] = h;
-        if (wt) wt[(long)j * npad + o] = h;
-        if (j == 0) bp[o] = (r >= 0 && bias) ? bias[r] : 0.0f;
-    }
-}
-}  // namespace
-
-extern "C" int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
-                                         void *wp, void *wt, float *bp, void *stream)
-{
-    if (!w || !wp || !bp || n <= 0 || k <= 0 || npad < n || kp < k || gap < 0) return PCB_ERR_INVALID_ARG;
-    const int blocks = (npad * kp + 255) / 256;
-    hipLaunchKernelGGL(prep_linear_bias_kernel, dim3(blocks < 64 ? blocks : 64), dim3(256), 0, (hipStream_t)stream, w, bias,
-                       n, k, npad, kp, gap, (u16 *)wp, (u16 *)wt, bp);
     return pcb_check_launch();
 }
 
@@ -1083,128 +866,18 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
     return pcb_check_launch();
 }
 
-extern "C" int pcb_set_concurrency_hint(int busy_cus)
-{
-    g_shared_cus = busy_cus < 0 ? 0 : (busy_cus > 64 ? 64 : busy_cus);
-    return PCB_OK;
-}
-
-extern "C" int pcb_gemm_nt_partials(int pro, long R, int N)
-{
-    if (R <= 0 || N <= 0 || pro < 0 || pro > 3) return 0;
-    return (int)nt_grid_x(pro, R, N);
-}
-
-// Deferred slab reductions (see reduce_slabs_multi_kernel): between begin and flush every
-// pcb_gemm_tn_bf16 on this thread needs its OWN workspace region.
-void pcb_defer_reduces_begin() { g_npending = 0; }
-
-int pcb_defer_reduces_flush(hipStream_t st)
-{
-    const int n = g_npending;
-    g_npending = -1;
-    if (n <= 0) return PCB_OK;
-    long most = 0;
-    for (int i = 0; i < n; ++i) most = g_pending.e[i].elems > most ? g_pending.e[i].elems : most;
-    long blocks = (most + 63) / 64;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(1024), 0, st, g_pending);
-    return pcb_check_launch();
-}
-
-extern "C" long pcb_gemm_tn_workspace(long R, int M, int N)
-{
-    if (R <= 0 || M <= 0 || N <= 0) return 0;
-    long rps;
-    return tn_splits(R, M, N, &rps) * (long)M * N;
-}
-
-extern "C" int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *scale,
-                                   const float *mean, const float *invstd, int use_batch_stats, float *p,
-                                   float *q, float *dgamma, float *dbeta, float *dbias, void *stream)
-{
-    if (!sums || nparts < 1 || !scale || !mean || !invstd || !p || !q || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums,
-                       nparts, rows, C, scale, mean, invstd, use_batch_stats, p, q, dgamma, dbeta, dbias);
-    return pcb_check_launch();
-}
-
-// ---- weight preparation -------------------------------------------------------------------------
-// The fp32 master weights of up to PREP_MAX layers become, in ONE launch, the bf16 operands the
-// GEMMs read: wp [C, kp] in the padded column layout of the layer's input rows (real_column) and,
-// for the input-gradient GEMM, its transpose wt [kp, C].
-namespace {
-constexpr int PREP_MAX = 8;
-struct PrepLayer {
-    const float *w;   // [C, k] fp32
-    u16 *wp;          // [C, kp] bf16
-    u16 *wt;          // [kp, C] bf16 or NULL
-    int C, k, kp, perm;
-};
-struct PrepArgs {
-    PrepLayer l[PREP_MAX];
-    float *zero;   // optional: a float buffer cleared by the same launch (a stack's constants)
-    long zero_n;
-};
-
-__global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs args)
-{
-    if (blockIdx.y == 0)
-        for (long e = blockIdx.x * 256 + threadIdx.x; e < args.zero_n; e += gridDim.x * 256) args.zero[e] = 0.0f;
-    const PrepLayer L = args.l[blockIdx.y];
-    const int total = L.C * L.kp;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int c = e / L.kp, j = e - c * L.kp;
-        const int r = real_column(j, L.k, L.perm);
-        const u16 h = r >= 0 ? f2bf(L.w[(long)c * L.k + r]) : (u16)0;
-        L.wp[e] = h;
-        if (L.wt) L.wt[(long)j * L.C + c] = h;
-    }
-}
-}  // namespace
-
-extern "C" int pcb_prep_weights_bf16(int n, const long long *desc, void *stream)
-{
-    return pcb_prep_weights_zero_bf16(n, desc, nullptr, 0, stream);
-}
-
-extern "C" int pcb_prep_weights_zero_bf16(int n, const long long *desc, float *zero, long zero_n, void *stream)
-{
-    if (n < 1 || n > PREP_MAX || !desc || zero_n < 0 || (zero_n && !zero)) return PCB_ERR_INVALID_ARG;
-    PrepArgs a;
-    a.zero = zero;
-    a.zero_n = zero_n;
-    int most = 0;
-    for (int i = 0; i < n; ++i) {
-        const long long *d = desc + 8 * i;
-        a.l[i].w = (const float *)d[0];
-        a.l[i].wp = (u16 *)d[1];
-        a.l[i].wt = (u16 *)d[2];
-        a.l[i].C = (int)d[3];
-        a.l[i].k = (int)d[4];
-        a.l[i].kp = (int)d[5];
-        a.l[i].perm = (int)d[6];
-        if (!a.l[i].w || !a.l[i].wp || a.l[i].C <= 0 || a.l[i].k <= 0 || a.l[i].kp < a.l[i].k) return PCB_ERR_INVALID_ARG;
-        if (a.l[i].C * a.l[i].kp > most) most = a.l[i].C * a.l[i].kp;
-    }
-    int gx = (most + 255) / 256;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(prep_weights_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
-    return pcb_check_launch();
-}
-
 // pcb_gemm_nt_bf16 for an input-gradient GEMM (pro 2 or 3) that ALSO accumulates the BatchNorm
-// backward sums of the layer below (see RedArgs): red_sums is [pcb_gemm_nt_partials(pro,R,N)][2][N].
-// Falls back to the plain kernel + no sums (returns 1) when the wide-output variant applies.
+// backward sums of the layer below (see RedArgs): red_sums is [nparts][2][N], one slab per workgroup along x.
 extern "C" int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, const float *scale,
                                     const float *shift, const float *p, const float *q, const float *dout,
                                     const unsigned char *argmax, int ns, int act, const void *w, long R, int N,
                                     int K, void *out, const void *red_y, const float *red_scale,
                                     const float *red_shift, const float *red_mean, const float *red_invstd,
-                                    int red_act, float *red_sums, void *stream)
+                                    int red_act, float *red_sums, int nparts, void *stream)
 {
     if (!w || !out || R <= 0 || !red_y || !red_scale || !red_shift || !red_mean || !red_invstd || !red_sums)
         return PCB_ERR_INVALID_ARG;
+    if (nparts < 1 || nparts > PCB_MAX_SLABS) return PCB_ERR_INVALID_ARG;
     if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
     if (pro != PRO_DY && pro != PRO_DY_POOL) return PCB_ERR_INVALID_ARG;
     if (!a1 || !scale || !shift || !p || !q || (pro == PRO_DY && !a0)) return PCB_ERR_INVALID_ARG;
@@ -1216,9 +889,9 @@ extern "C" int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, con
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);
     if (pro == PRO_DY)
-        launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, st, &red);
+        launch_nt<PRO_DY>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, nparts, st, &red);
     else
-        launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, st, &red);
+        launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, red_sums, nparts, st, &red);
     pcb_timer_end(st, timed, nt_bytes(pro, R, N, K, ns) + 2.0 * R * N, pro + 10, R, N, K);
     return pcb_check_launch();
 }

@@ -1,0 +1,381 @@
+// Pieces shared by the bf16 and the fp32 row GEMMs of the shared pointwise MLPs (gemm.hip,
+// gemm_f32.hip): grid / slab sizing and the concurrency hint, the fixed-order slab sums behind the
+// weight-gradient GEMMs, the BatchNorm-backward finalize kernel and the one-launch operand
+// preparation from the fp32 master weights of the caller's stock nn.Conv modules
+// (models/pointnet2_utils.py:138-142, :166-170, :313-323; models/DGCNN.py:19-33).
+#include <stdlib.h>
+
+#include <atomic>
+
+#include "gemm_shared.h"
+#include "rowvec.h"
+
+namespace {
+
+// Column layouts of a padded GEMM operand [.., kp] against the layer's real weight [.., k]
+// (host side: rowmlp.padded_weight_from).  Returns the real column a padded column j holds, or -1
+// for padding.
+//   perm = 0      real columns in place, zero padded on the right
+//   perm = C > 0  grouped rows (pcb_group_rows_*): the C feature columns first, then the 3
+//                 centred coordinates (real order: coordinates first)
+//   perm = -D < 0 interpolate+concat rows: the first D columns in place, the rest from pad(D), the
+//                 next multiple of `quantum` (8 columns for bf16 rows, 4 for fp32 rows: 16 bytes)
+__device__ __forceinline__ int real_column(int j, int k, int perm, int quantum)
+{
+    if (perm > 0) return j < perm ? 3 + j : (j < perm + 3 ? j - perm : -1);
+    if (perm < 0) {
+        const int d = -perm, dp = (d + quantum - 1) / quantum * quantum;
+        if (j < d) return j;
+        const int r = d + (j - dp);
+        return (j >= dp && r < k) ? r : -1;
+    }
+    return j < k ? j : -1;
+}
+
+// dW = sum over splits of part[s], in a fixed order (bitwise reproducible weight gradient), written
+// in the real weight layout [M, k] (padding columns dropped, see real_column).
+// 64 consecutive elements x 16 split-lanes per workgroup: coalesced slab reads, LDS tree at the end.
+// Up to kMaxPending sums in ONE launch (blockIdx.y = entry): a stack's backward pass parks the
+// reductions of its layers (nothing in that pass reads dW) and runs them together at its end
+// instead of one 5-10 us launch behind every weight-gradient GEMM.
+constexpr int kMaxPending = 16;
+struct PendingReduce {
+    const float *part;
+    float *dW;
+    long elems;
+    int splits, N, k, perm, quantum;
+};
+struct ReduceBatch {
+    PendingReduce e[kMaxPending];
+};
+__global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch batch)
+{
+    __shared__ float red[16][64];
+    const PendingReduce r = batch.e[blockIdx.y];
+    const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    for (long e0 = (long)blockIdx.x * 64; e0 < r.elems; e0 += (long)gridDim.x * 64) {
+        const long e = e0 + ex;
+        float a = 0.0f;
+        if (e < r.elems)
+            for (int s = sy; s < r.splits; s += 16) a += r.part[(long)s * r.elems + e];
+        red[sy][ex] = a;
+        __syncthreads();
+        if (sy == 0 && e < r.elems) {
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += red[i][ex];
+            const long m = e / r.N;
+            const int c = real_column((int)(e - m * r.N), r.k, r.perm, r.quantum);
+            if (c >= 0) r.dW[m * r.k + c] = t;
+        }
+        __syncthreads();
+    }
+}
+thread_local ReduceBatch g_pending;
+thread_local int g_npending = -1;  // < 0: every reduction runs right behind its GEMM (the default)
+
+int launch_reduce_batch(const ReduceBatch &batch, int n, hipStream_t st)
+{
+    long most = 0;
+    for (int i = 0; i < n; ++i) most = batch.e[i].elems > most ? batch.e[i].elems : most;
+    long blocks = (most + 63) / 64;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(1024), 0, st, batch);
+    return pcb_check_launch();
+}
+
+// p, q of the fused BatchNorm backward of one layer from sums = [nparts][2][C] partial slabs of
+// (sum du, sum du*xhat); the parameter gradients the totals amount to go to dgamma, dbeta, dbias
+// ([C] each, optional): dbeta = s1, dgamma = s2, dbias = 0 under batch statistics (the mean
+// subtraction cancels a bias exactly), scale*s1 otherwise.
+// gsums (optional, [2][C]): the same two sums over ALL ranks' rows (SyncBatchNorm: `rows` then
+// counts all ranks' rows): p and q come from them, the parameter gradients stay local.
+// Block = 32 channels x 32 slab-lanes.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(float *__restrict__ sums, int nparts,
+                                                                const float *__restrict__ gsums, long rows, int C,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd,
+                                                                int use_batch_stats, float *__restrict__ p,
+                                                                float *__restrict__ q, float *__restrict__ dgamma,
+                                                                float *__restrict__ dbeta, float *__restrict__ dbias)
+{
+    __shared__ float red[2][32][32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s1 = 0.0f, s2 = 0.0f;
+    if (c < C) {
+        for (int k = pl; k < nparts; k += 32) {
+            s1 += sums[((long)k * 2 + 0) * C + c];
+            s2 += sums[((long)k * 2 + 1) * C + c];
+        }
+    }
+    red[0][pl][cl] = s1;
+    red[1][pl][cl] = s2;
+    __syncthreads();
+    if (pl != 0 || c >= C) return;
+    s1 = 0.0f;
+    s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        s1 += red[0][k][cl];
+        s2 += red[1][k][cl];
+    }
+    if (nparts == 1) {
+        // a single slab was accumulated with atomics: leave it cleared for the next accumulation
+        sums[c] = 0.0f;
+        sums[C + c] = 0.0f;
+    }
+    if (dgamma) dgamma[c] = s2;
+    if (dbeta) dbeta[c] = s1;
+    if (dbias) dbias[c] = use_batch_stats ? 0.0f : scale[c] * s1;
+    if (!use_batch_stats) {
+        p[c] = 0.0f;
+        q[c] = 0.0f;
+        return;
+    }
+    if (gsums) {
+        s1 = gsums[c];
+        s2 = gsums[C + c];
+    }
+    const float invR = 1.0f / (float)rows;
+    const float a = s1 * invR;       // mean of du
+    const float b = s2 * invR;       // mean of du * xhat
+    const float sb = scale[c] * b * invstd[c];
+    p[c] = -sb;
+    q[c] = fmaf(sb, mean[c], -scale[c] * a);
+}
+
+// CUs to leave free while another kernel runs beside the backward pass (pcb_set_concurrency_hint).
+// Measured with the FPS kernel of the next batch on a side stream (16 workgroups): a 512-workgroup
+// persistent gemm_nt slows from 145 to 220 us, one of 448 runs in 163 us either way -- the persistent
+// grid assumes it owns every CU, and the workgroups that find their CU taken serialise behind others.
+// The only mutable state of the library besides the roofline timer: a hint, read once per entry
+// point, that can change grid sizes but never which buffers a launch may touch (slab counts are
+// explicit arguments).
+std::atomic<int> g_shared_cus{0};
+
+// Tuning knobs for the persistent grids, clamped to [64, PCB_MAX_SLABS].
+long grid_knob(const char *name, long def)
+{
+    const char *e = getenv(name);
+    const long v = e ? atol(e) : def;
+    return v < 64 ? 64L : (v > PCB_MAX_SLABS ? (long)PCB_MAX_SLABS : v);
+}
+
+// ---- weight preparation -------------------------------------------------------------------------
+// The fp32 master weights of up to PREP_MAX layers become, in ONE launch, the operands the GEMMs
+// read (bf16 or fp32 rows): wp [C, kp] in the padded column layout of the layer's input rows
+// (real_column) and, for the input-gradient GEMM, its transpose wt [kp, C].
+constexpr int PREP_MAX = 8;
+struct PrepLayer {
+    const float *w;   // [C, k] fp32
+    void *wp;         // [C, kp]
+    void *wt;         // [kp, C] or NULL
+    int C, k, kp, perm;
+};
+struct PrepArgs {
+    PrepLayer l[PREP_MAX];
+    float *zero;   // optional: a float buffer cleared by the same launch (a stack's constants)
+    long zero_n;
+};
+
+template <typename T>
+__device__ __forceinline__ T to_elem(float f);
+template <>
+__device__ __forceinline__ pcb_bf16 to_elem<pcb_bf16>(float f) { return pcb_f2bf(f); }
+template <>
+__device__ __forceinline__ float to_elem<float>(float f) { return f; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs args)
+{
+    if (blockIdx.y == 0)
+        for (long e = blockIdx.x * 256 + threadIdx.x; e < args.zero_n; e += gridDim.x * 256) args.zero[e] = 0.0f;
+    const PrepLayer L = args.l[blockIdx.y];
+    T *const wp = (T *)L.wp;
+    T *const wt = (T *)L.wt;
+    const int total = L.C * L.kp;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int c = e / L.kp, j = e - c * L.kp;
+        const int r = real_column(j, L.k, L.perm, RowVec<T>::E);
+        const T h = to_elem<T>(r >= 0 ? L.w[(long)c * L.k + r] : 0.0f);
+        wp[e] = h;
+        if (wt) wt[(long)j * L.C + c] = h;
+    }
+}
+
+template <typename T>
+int prep_weights(int n, const long long *desc, float *zero, long zero_n, void *stream)
+{
+    if (n < 1 || n > PREP_MAX || !desc || zero_n < 0 || (zero_n && !zero)) return PCB_ERR_INVALID_ARG;
+    PrepArgs a;
+    a.zero = zero;
+    a.zero_n = zero_n;
+    int most = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long *d = desc + 8 * i;
+        a.l[i].w = (const float *)d[0];
+        a.l[i].wp = (void *)d[1];
+        a.l[i].wt = (void *)d[2];
+        a.l[i].C = (int)d[3];
+        a.l[i].k = (int)d[4];
+        a.l[i].kp = (int)d[5];
+        a.l[i].perm = (int)d[6];
+        if (!a.l[i].w || !a.l[i].wp || a.l[i].C <= 0 || a.l[i].k <= 0 || a.l[i].kp < a.l[i].k) return PCB_ERR_INVALID_ARG;
+        if (a.l[i].C * a.l[i].kp > most) most = a.l[i].C * a.l[i].kp;
+    }
+    int gx = (most + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(prep_weights_kernel<T>, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
+    return pcb_check_launch();
+}
+
+// Operands of a bias-only conv in one launch: w [n,k] fp32 -> wp [npad,kp] and wt [kp,npad] (zero
+// padded), bias [n] -> bp [npad] fp32.  gap = D > 0: the n outputs use the interpolate+concat
+// column layout (first D in place, the rest from column pad(D)), see real_column(.., -D).
+template <typename T>
+__global__ __launch_bounds__(256) void prep_linear_bias_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                               int n, int k, int npad, int kp, int gap,
+                                                               T *__restrict__ wp, T *__restrict__ wt,
+                                                               float *__restrict__ bp)
+{
+    const int total = npad * kp;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int o = e / kp, j = e - o * kp;
+        const int r = real_column(o, n, -gap, RowVec<T>::E);   // gap = 0: o < n ? o : -1
+        const T h = to_elem<T>((r >= 0 && j < k) ? w[(long)r * k + j] : 0.0f);
+        wp[e] = h;
+        if (wt) wt[(long)j * npad + o] = h;
+        if (j == 0) bp[o] = (r >= 0 && bias) ? bias[r] : 0.0f;
+    }
+}
+
+template <typename T>
+int prep_linear_bias(const float *w, const float *bias, int n, int k, int npad, int kp, int gap, void *wp, void *wt,
+                     float *bp, void *stream)
+{
+    if (!w || !wp || !bp || n <= 0 || k <= 0 || npad < n || kp < k || gap < 0) return PCB_ERR_INVALID_ARG;
+    const int blocks = (npad * kp + 255) / 256;
+    hipLaunchKernelGGL(prep_linear_bias_kernel<T>, dim3(blocks < 64 ? blocks : 64), dim3(256), 0, (hipStream_t)stream, w,
+                       bias, n, k, npad, kp, gap, (T *)wp, (T *)wt, bp);
+    return pcb_check_launch();
+}
+
+}  // namespace
+
+int pcb_busy_cus() { return g_shared_cus.load(std::memory_order_relaxed); }
+
+long pcb_nt_grid_x(int pro, long R, int N, int busy_cus)
+{
+    const long tiles = (R + PCB_NT_BM - 1) / PCB_NT_BM;
+    const long ny = (N + PCB_NT_BN - 1) / PCB_NT_BN;
+    static const long fwd_chip = grid_knob("PCB_NT_FWD_GRID", 768);
+    static const long bwd_chip = grid_knob("PCB_NT_BWD_GRID", 512);
+    // while another kernel holds CUs the persistent grids leave them alone: 3 forward / 2 backward
+    // workgroups fit a CU
+    long chip = pro <= PCB_PRO_BNACT ? fwd_chip - 3L * busy_cus : bwd_chip - 2L * busy_cus;
+    if (chip < 64) chip = 64;
+    const long resident = chip / ny > 0 ? chip / ny : 1;
+    return tiles < resident ? tiles : resident;
+}
+
+long pcb_tn_splits(long R, int M, int N, long *rows_per_split, long target)
+{
+    const long tiles = (long)((M + PCB_TN_BM - 1) / PCB_TN_BM) * ((N + PCB_TN_BN - 1) / PCB_TN_BN);
+    if (target < 64) target = 64;
+    long splits = (target + tiles - 1) / tiles;
+    const long max_splits = (R + 8 * PCB_TN_RS - 1) / (8 * PCB_TN_RS);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long rps = (R + splits - 1) / splits;
+    rps = (rps + PCB_TN_RS - 1) / PCB_TN_RS * PCB_TN_RS;
+    *rows_per_split = rps;
+    return (R + rps - 1) / rps;
+}
+
+int pcb_reduce_slabs(const float *part, int splits, long elems, float *dW, int N, int out_cols, int out_perm,
+                     int quantum, hipStream_t st)
+{
+    const PendingReduce r = {part, dW, elems, splits, N, out_cols, out_perm, quantum};
+    if (g_npending >= 0 && g_npending < kMaxPending) {
+        g_pending.e[g_npending++] = r;
+        return PCB_OK;
+    }
+    ReduceBatch one;
+    one.e[0] = r;
+    return launch_reduce_batch(one, 1, st);
+}
+
+// Deferred slab reductions (see reduce_slabs_multi_kernel): between begin and flush every
+// weight-gradient GEMM on this thread needs its OWN workspace region.
+void pcb_defer_reduces_begin() { g_npending = 0; }
+
+int pcb_defer_reduces_flush(hipStream_t st)
+{
+    const int n = g_npending;
+    g_npending = -1;
+    if (n <= 0) return PCB_OK;
+    return launch_reduce_batch(g_pending, n, st);
+}
+
+extern "C" {
+
+int pcb_set_concurrency_hint(int busy_cus)
+{
+    g_shared_cus.store(busy_cus < 0 ? 0 : (busy_cus > 64 ? 64 : busy_cus), std::memory_order_relaxed);
+    return PCB_OK;
+}
+
+int pcb_gemm_nt_partials(int pro, long R, int N)
+{
+    if (R <= 0 || N <= 0 || pro < 0 || pro > 3) return 0;
+    return (int)pcb_nt_grid_x(pro, R, N, pcb_busy_cus());
+}
+
+long pcb_gemm_tn_workspace(long R, int M, int N)
+{
+    if (R <= 0 || M <= 0 || N <= 0) return 0;
+    long rps;
+    return pcb_tn_splits(R, M, N, &rps, 512) * (long)M * N;
+}
+
+int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *scale, const float *mean,
+                        const float *invstd, int use_batch_stats, float *p, float *q, float *dgamma, float *dbeta,
+                        float *dbias, const float *global_sums, void *stream)
+{
+    if (!sums || nparts < 1 || !scale || !mean || !invstd || !p || !q || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums,
+                       nparts, global_sums, rows, C, scale, mean, invstd, use_batch_stats, p, q, dgamma, dbeta, dbias);
+    return pcb_check_launch();
+}
+
+int pcb_prep_weights_bf16(int n, const long long *desc, void *stream)
+{
+    return prep_weights<pcb_bf16>(n, desc, nullptr, 0, stream);
+}
+int pcb_prep_weights_zero_bf16(int n, const long long *desc, float *zero, long zero_n, void *stream)
+{
+    return prep_weights<pcb_bf16>(n, desc, zero, zero_n, stream);
+}
+int pcb_prep_weights_f32(int n, const long long *desc, void *stream)
+{
+    return prep_weights<float>(n, desc, nullptr, 0, stream);
+}
+int pcb_prep_weights_zero_f32(int n, const long long *desc, float *zero, long zero_n, void *stream)
+{
+    return prep_weights<float>(n, desc, zero, zero_n, stream);
+}
+
+int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap, void *wp,
+                              void *wt, float *bp, void *stream)
+{
+    return prep_linear_bias<pcb_bf16>(w, bias, n, k, npad, kp, gap, wp, wt, bp, stream);
+}
+int pcb_prep_linear_bias_f32(const float *w, const float *bias, int n, int k, int npad, int kp, int gap, void *wp,
+                             void *wt, float *bp, void *stream)
+{
+    return prep_linear_bias<float>(w, bias, n, k, npad, kp, gap, wp, wt, bp, stream);
+}
+
+}  // extern "C"

@@ -20,7 +20,7 @@
 #include <utility>
 #include <vector>
 
-#include "pcb_common.h"
+#include "gemm_shared.h"
 
 // ---- roofline timer -------------------------------------------------------------------------
 namespace {
@@ -145,15 +145,37 @@ struct Layer {
     float *dW, *dgamma, *dbeta, *dbias;
     long long *nbt;  // num_batches_tracked or NULL
     int kp;          // padded input width (= previous layer's C, or the stack's Kp)
-    long wp_off;     // element offsets into the bf16 weight buffer
+    long wp_off;     // element offsets into the weight buffer
     long wt_off;     // -1: no transposed copy
     long st_off;     // float offset of this layer's [10][C] constants
+};
+
+// The kernels of one arithmetic mode (PCB_DTYPE_BF16: gemm.hip + rowbn.hip *_bf16; PCB_DTYPE_F32:
+// gemm_f32.hip + rowbn.hip *_f32).  The runtime below is the same for both: only the storage type
+// of the rows differs.
+struct Ops {
+    int quantum;      // columns per 16-byte chunk: widths are multiples of it
+    size_t elem;      // bytes per row element
+    decltype(&pcb_prep_weights_zero_bf16) prep_zero;
+    decltype(&pcb_gemm_nt_bf16) gemm_nt;
+    decltype(&pcb_gemm_nt_red_bf16) gemm_nt_red;
+    decltype(&pcb_gemm_tn_bf16) gemm_tn;
+    decltype(&pcb_bn_act_bf16) bn_act;
+    decltype(&pcb_bn_act_max_bf16) bn_act_max;
+    decltype(&pcb_bn_act_bwd_reduce_bf16) bwd_reduce;
+    decltype(&pcb_bn_act_max_bwd_reduce_bf16) max_bwd_reduce;
+};
+const Ops kOps[2] = {
+    {8, 2, pcb_prep_weights_zero_bf16, pcb_gemm_nt_bf16, pcb_gemm_nt_red_bf16, pcb_gemm_tn_bf16, pcb_bn_act_bf16,
+     pcb_bn_act_max_bf16, pcb_bn_act_bwd_reduce_bf16, pcb_bn_act_max_bwd_reduce_bf16},
+    {4, 4, pcb_prep_weights_zero_f32, pcb_gemm_nt_f32, pcb_gemm_nt_red_f32, pcb_gemm_tn_f32, pcb_bn_act_f32,
+     pcb_bn_act_max_f32, pcb_bn_act_bwd_reduce_f32, pcb_bn_act_max_bwd_reduce_f32},
 };
 
 template <typename T>
 T *ptr(long long v) { return reinterpret_cast<T *>(static_cast<uintptr_t>(v)); }
 
-int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, Layer *out)
+int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, int quantum, Layer *out)
 {
     if (L < 1 || L > PCB_STACK_MAX_LAYERS || !desc) return PCB_ERR_INVALID_ARG;
     long woff = 0, soff = 0;
@@ -178,7 +200,7 @@ int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, Lay
         a.nbt = ptr<long long>(d[S_NBT]);
         if (gathered && l == 0) {
             // layer 0 = gather_add of per-point products: no weights of its own in this call
-            if (!a.y || a.C <= 0 || (a.C & 7)) return PCB_ERR_INVALID_ARG;
+            if (!a.y || a.C <= 0 || (a.C % quantum)) return PCB_ERR_INVALID_ARG;
             a.kp = 0;
             a.wp_off = woff;
             a.wt_off = -1;
@@ -187,7 +209,7 @@ int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, Lay
             kp = a.C;
             continue;
         }
-        if (!a.w || !a.y || a.C <= 0 || (a.C & 7) || a.k <= 0 || a.k > kp || (kp & 7)) return PCB_ERR_INVALID_ARG;
+        if (!a.w || !a.y || a.C <= 0 || (a.C % quantum) || a.k <= 0 || a.k > kp || (kp % quantum)) return PCB_ERR_INVALID_ARG;
         a.kp = kp;
         a.wp_off = woff;
         woff += (long)a.C * kp;
@@ -235,6 +257,15 @@ SideStream *side_stream()
     SideStream &s = per_device[dev];
     if (!s.st && !s.failed && hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) s.failed = true;
     return s.failed ? nullptr : &s;
+}
+
+// Slabs a gemm_nt launch of this stack gets: the library's preference for the concurrency hint read
+// at the top of the call, capped by what the caller's `parts` buffer holds.  The same number goes to
+// the GEMM (its grid) and to the finalize kernel that adds the slabs.
+inline int slabs_for(int pro, long R, int C, int busy, int parts_slabs)
+{
+    const long want = pcb_nt_grid_x(pro, R, C, busy);
+    return (int)(want < parts_slabs ? want : parts_slabs);
 }
 }  // namespace
 
@@ -284,15 +315,18 @@ bool parse_gather(const long long *g, Gather *out)
 }
 }  // namespace
 
-extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double *fdesc, const void *x, long R,
-                                     int Kp, int perm, int act, int pool, int need_wt0, int stat_repeat,
-                                     const long long *gather, void *wbuf, float *stz,
-                                     float *parts, void *out, unsigned char *argmax, void *stream)
+extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, const double *fdesc, const void *x,
+                                     long R, int Kp, int perm, int act, int pool, int need_wt0, int stat_repeat,
+                                     const long long *gather, void *wbuf, float *stz, float *parts, int parts_slabs,
+                                     const pcb_sync *sync, void *out, unsigned char *argmax, void *stream)
 {
+    if (dtype != PCB_DTYPE_BF16 && dtype != PCB_DTYPE_F32) return PCB_ERR_INVALID_ARG;
+    const Ops &op = kOps[dtype];
     Layer ly[PCB_STACK_MAX_LAYERS];
     Gather ga;
     const bool gathered = parse_gather(gather, &ga);
     if (gathered) {
+        if (dtype != PCB_DTYPE_BF16) return PCB_ERR_UNSUPPORTED;  // the gathered first layer exists for bf16 rows
         if (!ga.u || !ga.idx || (long)ga.B * ga.S * ga.ns != R || !parts) return PCB_ERR_INVALID_ARG;
         Kp = 0;
     }
@@ -300,21 +334,24 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
     // eval-mode call prepared from the same, unchanged parameters -- no preparation, no finalize
     const bool ready = (need_wt0 & 2) != 0;
     need_wt0 &= 1;
-    PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, ly));
+    PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, op.quantum, ly));
     if (!fdesc || (!x && !gathered) || (!wbuf && !(gathered && L == 1)) || !stz || !out || R <= 0 || pool < 0 ||
         (pool && (!argmax || R % pool)))
         return PCB_ERR_INVALID_ARG;
+    if (parts && parts_slabs < 1) return PCB_ERR_INVALID_ARG;
+    if (sync && (!sync->allreduce || sync->global_rows < R || !parts)) return PCB_ERR_INVALID_ARG;
     if (ready)
         for (int l = 0; l < L; ++l)
             if (ly[l].training) return PCB_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    unsigned short *wb = (unsigned short *)wbuf;
+    char *wb = (char *)wbuf;
+    const int busy = pcb_busy_cus();  // one reading of the hint for the whole call
 
     long stz_floats = 0;
     for (int l = 0; l < L; ++l) stz_floats += 10L * ly[l].C;
     bool cleared = ready;  // stz is cleared by the first weight-preparation launch (or a memset if there is none)
 
-    // bf16 operands of all layers (chunks of 8 layers per launch)
+    // GEMM operands of all layers (chunks of 8 layers per launch)
     for (int l0 = gathered ? 1 : 0; l0 < L && !ready; l0 += 8) {
         const int n = L - l0 < 8 ? L - l0 : 8;
         long long pd[8 * 8];
@@ -322,15 +359,15 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
             const Layer &a = ly[l0 + i];
             long long *d = pd + 8 * i;
             d[0] = (long long)(uintptr_t)a.w;
-            d[1] = (long long)(uintptr_t)(wb + a.wp_off);
-            d[2] = a.wt_off >= 0 ? (long long)(uintptr_t)(wb + a.wt_off) : 0;
+            d[1] = (long long)(uintptr_t)(wb + a.wp_off * op.elem);
+            d[2] = a.wt_off >= 0 ? (long long)(uintptr_t)(wb + a.wt_off * op.elem) : 0;
             d[3] = a.C;
             d[4] = a.k;
             d[5] = a.kp;
             d[6] = (l0 + i == 0) ? perm : 0;
             d[7] = 0;
         }
-        PCB_TRY(pcb_prep_weights_zero_bf16(n, pd, cleared ? nullptr : stz, cleared ? 0 : stz_floats, stream));
+        PCB_TRY(op.prep_zero(n, pd, cleared ? nullptr : stz, cleared ? 0 : stz_floats, stream));
         cleared = true;
     }
     if (!cleared && hipMemsetAsync(stz, 0, stz_floats * sizeof(float), st) != hipSuccess) return PCB_ERR_LAUNCH;
@@ -344,56 +381,76 @@ extern "C" int pcb_mlp_stack_forward(int L, const long long *desc, const double 
         const float *pshift = l ? row(stz, ly[l - 1], 3) : nullptr;
         int nparts;
         if (gathered && l == 0) {
+            const int want = pcb_gather_add_partials(R, a.C);
+            nparts = want < parts_slabs ? want : parts_slabs;
             PCB_TRY(pcb_gather_add_bf16(ga.u, ga.v, ga.idx, ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.wx, ga.ldw,
-                                        a.y, parts, stream));
-            nparts = pcb_gather_add_partials(R, a.C);
+                                        a.y, parts, nparts, stream));
         } else {
-            PCB_TRY(pcb_gemm_nt_bf16(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0,
-                                     act, wb + a.wp_off, R, a.C, a.kp, a.y, stats ? parts : nullptr, stream));
-            nparts = pcb_gemm_nt_partials(l ? 1 : 0, R, a.C);
+            nparts = stats ? slabs_for(l ? 1 : 0, R, a.C, busy, parts_slabs) : 0;
+            PCB_TRY(op.gemm_nt(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0, act,
+                               wb + a.wp_off * op.elem, R, a.C, a.kp, a.y, stats ? parts : nullptr, nparts, stream));
         }
-        if (!ready)
-            PCB_TRY(pcb_bn_finalize(stats ? parts : nullptr, nparts, R, R * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma,
+        if (!ready) {
+            const float *sums = stats ? parts : nullptr;
+            long rows = R;
+            if (stats && sync) {
+                // SyncBatchNorm: the local totals (2C floats) travel through the caller's all-reduce;
+                // the finalize kernel then sees the statistics of all ranks' rows
+                float *tot = row(stz, a, 0);
+                PCB_TRY(pcb_sum_slabs(parts, nparts, 2 * a.C, tot, stream));
+                if (sync->allreduce(tot, 2 * a.C, sync->ctx) != 0) return PCB_ERR_LAUNCH;
+                sums = tot;
+                nparts = 1;
+                rows = sync->global_rows;
+            }
+            PCB_TRY(pcb_bn_finalize(sums, nparts, rows, rows * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma,
                                     a.beta, a.bias, a.rmean, a.rvar, (float)fdesc[2 * l], (float)fdesc[2 * l + 1],
                                     a.training, row(stz, a, 2), row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), a.nbt,
                                     stream));
+        }
         cur = a.y;
     }
     const Layer &last = ly[L - 1];
     if (pool)
-        PCB_TRY(pcb_bn_act_max_bf16(cur, row(stz, last, 2), row(stz, last, 3), R / pool, pool, last.C, act, out, argmax,
-                                    stream));
+        PCB_TRY(op.bn_act_max(cur, row(stz, last, 2), row(stz, last, 3), R / pool, pool, last.C, act, out, argmax, stream));
     else
-        PCB_TRY(pcb_bn_act_bf16(cur, row(stz, last, 2), row(stz, last, 3), R, last.C, act, out, stream));
+        PCB_TRY(op.bn_act(cur, row(stz, last, 2), row(stz, last, 3), R, last.C, act, out, stream));
     return PCB_OK;
 }
 
-extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *x, const void *g,
+extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, const void *x, const void *g,
                                       const unsigned char *argmax, long R, int Kp, int perm, int act, int pool,
                                       int need_wt0, const long long *gather, const void *wbuf, float *stz,
-                                      float *parts, float *workspace, void *dzbuf, void *dx, void *stream)
+                                      float *parts, int parts_slabs, const pcb_sync *sync, float *workspace,
+                                      void *dzbuf, void *dx, void *stream)
 {
+    if (dtype != PCB_DTYPE_BF16 && dtype != PCB_DTYPE_F32) return PCB_ERR_INVALID_ARG;
+    const Ops &op = kOps[dtype];
     Layer ly[PCB_STACK_MAX_LAYERS];
     Gather ga;
     const bool gathered = parse_gather(gather, &ga);
     if (gathered) {
+        if (dtype != PCB_DTYPE_BF16) return PCB_ERR_UNSUPPORTED;
         if (!ga.u || !ga.idx || (long)ga.B * ga.S * ga.ns != R || dx) return PCB_ERR_INVALID_ARG;
         Kp = 0;
     }
-    PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, ly));
+    PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, op.quantum, ly));
     if ((!x && !gathered) || !g || (!wbuf && !(gathered && L == 1)) || !stz || (!workspace && !(gathered && L == 1)) ||
         R <= 0 || (pool && !argmax))
         return PCB_ERR_INVALID_ARG;
     if (dx && !need_wt0) return PCB_ERR_INVALID_ARG;
-    const unsigned short *wb = (const unsigned short *)wbuf;
+    if (parts && parts_slabs < 1) return PCB_ERR_INVALID_ARG;
+    if (sync && (!sync->allreduce || sync->global_rows < R || !parts)) return PCB_ERR_INVALID_ARG;
+    const char *wb = (const char *)wbuf;
     int maxw = Kp > 8 ? Kp : 8;
     for (int l = 0; l + 1 < L; ++l) maxw = ly[l].C > maxw ? ly[l].C : maxw;
     if (L > 1 && !dzbuf) return PCB_ERR_INVALID_ARG;
+    const int busy = pcb_busy_cus();  // one reading of the hint for the whole call
 
     hipStream_t main_st = (hipStream_t)stream;
     SideStream *side = side_stream();
     hipEvent_t tn_done = nullptr;  // completion of the most recent gemm_tn on the side stream
-    const void *dz = pool ? nullptr : g;                 // dense upstream gradient (bf16 rows)
+    const void *dz = pool ? nullptr : g;                 // dense upstream gradient (rows)
     const float *dout = pool ? (const float *)g : nullptr;  // pooled upstream gradient (fp32)
     bool have_parts = false;  // sums of layer l already accumulated by the dgrad GEMM of layer l+1
     int have_nparts = 0;
@@ -420,13 +477,30 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
                 sums = parts;
                 nparts = have_nparts;
             } else if (pooled) {
-                PCB_TRY(pcb_bn_act_max_bwd_reduce_bf16(dout, argmax, a.y, scale, shift, mean, invstd, R / pool, pool,
-                                                       a.C, act, bsums, stream));
+                PCB_TRY(op.max_bwd_reduce(dout, argmax, a.y, scale, shift, mean, invstd, R / pool, pool, a.C, act, bsums,
+                                          stream));
             } else {
-                PCB_TRY(pcb_bn_act_bwd_reduce_bf16(dz, a.y, scale, shift, mean, invstd, R, a.C, act, bsums, stream));
+                PCB_TRY(op.bwd_reduce(dz, a.y, scale, shift, mean, invstd, R, a.C, act, bsums, stream));
             }
-            PCB_TRY(pcb_bn_bwd_finalize(sums, nparts, R, a.C, scale, mean, invstd, a.training, p, q, a.dgamma, a.dbeta,
-                                        a.dbias, stream));
+            const float *gsums = nullptr;
+            long rows = R;
+            if (sync && a.training) {
+                // SyncBatchNorm: p, q from the sums over all ranks' rows; dgamma / dbeta / dbias stay
+                // local (the gradient all-reduce averages them like every other parameter gradient)
+                float *tot = row(stz, a, 0);
+                PCB_TRY(pcb_sum_slabs(sums, nparts, 2 * a.C, tot, stream));
+                if (hipMemcpyAsync(parts, tot, sizeof(float) * 2 * a.C, hipMemcpyDeviceToDevice, main_st) != hipSuccess)
+                    return PCB_ERR_LAUNCH;
+                if (sync->allreduce(parts, 2 * a.C, sync->ctx) != 0) return PCB_ERR_LAUNCH;
+                if (sums == bsums && hipMemsetAsync(bsums, 0, sizeof(float) * 2 * a.C, main_st) != hipSuccess)
+                    return PCB_ERR_LAUNCH;  // what the finalize kernel does for a single atomically accumulated slab
+                sums = tot;
+                nparts = 1;
+                gsums = parts;
+                rows = sync->global_rows;
+            }
+            PCB_TRY(pcb_bn_bwd_finalize(sums, nparts, rows, a.C, scale, mean, invstd, a.training, p, q, a.dgamma, a.dbeta,
+                                        a.dbias, gsums, stream));
             have_parts = false;
             const int apro = pooled ? 3 : 2;
             const int ns = pooled ? pool : 1;
@@ -451,12 +525,11 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
                     tn_stream = side->st;
                 if (l) {
                     const Layer &b = ly[l - 1];
-                    PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 1, b.y,
-                                             row(stz, b, 2), row(stz, b, 3), act, R, a.C, a.kp, workspace + ws_off[l], a.dW,
-                                             a.k, 0, tn_stream));
+                    PCB_TRY(op.gemm_tn(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 1, b.y, row(stz, b, 2),
+                                       row(stz, b, 3), act, R, a.C, a.kp, workspace + ws_off[l], a.dW, a.k, 0, tn_stream));
                 } else {
-                    PCB_TRY(pcb_gemm_tn_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 0, x, nullptr,
-                                             nullptr, 0, R, a.C, a.kp, workspace + ws_off[l], a.dW, a.k, perm, tn_stream));
+                    PCB_TRY(op.gemm_tn(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, 0, x, nullptr, nullptr, 0,
+                                       R, a.C, a.kp, workspace + ws_off[l], a.dW, a.k, perm, tn_stream));
                 }
                 if (tn_stream != stream) {
                     tn_done = side->event();
@@ -466,18 +539,18 @@ extern "C" int pcb_mlp_stack_backward(int L, const long long *desc, const void *
             // input gradient
             if (l == 0 && !dx) return PCB_OK;
             if (tn_prev && hipStreamWaitEvent(main_st, tn_prev, 0) != hipSuccess) return PCB_ERR_LAUNCH;
-            void *dprev = l ? (void *)((unsigned short *)dzbuf + (long)(l & 1) * R * maxw) : dx;
-            const unsigned short *wt = wb + a.wt_off;
+            void *dprev = l ? (void *)((char *)dzbuf + (size_t)(l & 1) * R * maxw * op.elem) : dx;
+            const void *wt = wb + a.wt_off * op.elem;
             if (l && a.kp <= 128 && parts) {
                 const Layer &b = ly[l - 1];
-                PCB_TRY(pcb_gemm_nt_red_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C,
-                                             dprev, b.y, row(stz, b, 2), row(stz, b, 3), row(stz, b, 4), row(stz, b, 5),
-                                             act, parts, stream));
+                have_nparts = slabs_for(apro, R, a.kp, busy, parts_slabs);
+                PCB_TRY(op.gemm_nt_red(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C, dprev,
+                                       b.y, row(stz, b, 2), row(stz, b, 3), row(stz, b, 4), row(stz, b, 5), act, parts,
+                                       have_nparts, stream));
                 have_parts = true;
-                have_nparts = pcb_gemm_nt_partials(apro, R, a.kp);
             } else {
-                PCB_TRY(pcb_gemm_nt_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C,
-                                         dprev, nullptr, stream));
+                PCB_TRY(op.gemm_nt(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wt, R, a.kp, a.C, dprev,
+                                   nullptr, 0, stream));
             }
             dz = dprev;
             dout = nullptr;

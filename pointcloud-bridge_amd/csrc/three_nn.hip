@@ -6,7 +6,7 @@
 // three_nn: one lane per query point, candidates staged once per workgroup through LDS as
 // (x, y, z, |p|^2) float4 and read back as wave-wide broadcasts; the k best live in registers.
 // Equal distances keep ascending index order (the reference's CPU sort is stable).
-#include "pcb_common.h"
+#include "rowvec.h"
 
 namespace {
 
@@ -193,42 +193,30 @@ extern "C" int pcb_interpolate_bwd(const float *grad_out, const float *w, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// bf16 interpolation straight into a (padded, concatenated) GEMM input buffer, and its backward
-// as a segmented reduction over an inverted index instead of fp32 atomics.
+// Interpolation straight into a (padded, concatenated) GEMM input buffer, and its backward
+// as a segmented reduction over an inverted index instead of fp32 atomics -- for bf16 rows and for
+// fp32 rows (rowvec.h).
 //
 // FeaturePropagation.forward (models/pointnet2_utils.py:191-203) interpolates the coarse features
 // and concatenates them behind the skip features; here the interpolated columns are written at
-// their final place in the bf16 row buffer of the following GEMM.
+// their final place in the row buffer of the following GEMM.
 // Backward: grad_feat[b,s,:] = sum over (n,q) with idx[b,n,q] == s of w[b,n,q] * g[b,n,:].
 // The atomic form moves B*N*C*k fp32 adds to memory (1 GB at B=16, N=16384, C=256: atomic-rate
 // bound); the inverted index (counting sort of the (n,q) pairs by target s, ~1 M integers) lets one
 // wave sum each target's ~N*k/S contribution rows with plain coalesced 16-byte reads.
 namespace {
 
-typedef unsigned short u16_t;
-
-__device__ __forceinline__ void unpack8f(const uint4 &v, float *f)
-{
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-}
-__device__ __forceinline__ uint32_t pack2f(float a, float b)
-{
-    return (uint32_t)__builtin_bit_cast(u16_t, (__bf16)a) | ((uint32_t)__builtin_bit_cast(u16_t, (__bf16)b) << 16);
-}
-
-// one lane per (row, 8-channel chunk)
-template <int K>
-__global__ __launch_bounds__(256) void interpolate_bf16_kernel(const u16_t *__restrict__ feat,
+// one lane per (row, 16-byte channel chunk)
+template <typename T, int K>
+__global__ __launch_bounds__(256) void interpolate_rows_kernel(const T *__restrict__ feat,
                                                                 const float *__restrict__ d2,
                                                                 const int64_t *__restrict__ idx, int N, int S,
-                                                                int C, u16_t *__restrict__ out, int ld,
+                                                                int C, T *__restrict__ out, int ld,
                                                                 int col0, float *__restrict__ out_w,
                                                                 long nchunk)
 {
-    const int CT = C >> 3;
+    constexpr int E = RowVec<T>::E;
+    const int CT = C / E;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nchunk; e += (long)gridDim.x * 256) {
         const int cc = (int)(e % CT);
         const long row = e / CT;  // b*N + n
@@ -240,22 +228,28 @@ __global__ __launch_bounds__(256) void interpolate_bf16_kernel(const u16_t *__re
             w[k] = __fdiv_rn(1.0f, __fadd_rn(d2[row * K + k], 1e-8f));
             norm = k ? __fadd_rn(norm, w[k]) : w[k];
         }
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float acc[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) acc[i] = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             w[k] = __fdiv_rn(w[k], norm);
             const int j = clamp_index(idx[row * K + k], S);
-            float f[8];
-            unpack8f(*reinterpret_cast<const uint4 *>(feat + ((b * S + j) * (long)C + cc * 8)), f);
+            float f[E];
+            RowVec<T>::unpack(*reinterpret_cast<const uint4 *>(feat + ((b * S + j) * (long)C + cc * E)), f);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = fmaf(f[i], w[k], acc[i]);
+            for (int i = 0; i < E; ++i) {
+                if (E == 4) {
+                    // fp32 rows: product and sum rounded separately, in neighbour order -- the
+                    // reference's torch.sum(index_points(..) * weight, dim=2) (as interpolate_kernel)
+                    const float v = __fmul_rn(f[i], w[k]);
+                    acc[i] = k ? __fadd_rn(acc[i], v) : v;
+                } else {
+                    acc[i] = fmaf(f[i], w[k], acc[i]);
+                }
+            }
         }
-        uint4 o;
-        o.x = pack2f(acc[0], acc[1]);
-        o.y = pack2f(acc[2], acc[3]);
-        o.z = pack2f(acc[4], acc[5]);
-        o.w = pack2f(acc[6], acc[7]);
-        *reinterpret_cast<uint4 *>(out + row * (long)ld + col0 + cc * 8) = o;
+        *reinterpret_cast<uint4 *>(out + row * (long)ld + col0 + cc * E) = RowVec<T>::pack(acc);
         if (out_w && cc == 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) out_w[row * K + k] = w[k];
@@ -285,46 +279,79 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t *__restrict
     }
 }
 
-// one wave per target (b, s); a half-wave (32 lanes x 8 channels) covers up to 256 channels, wider
-// rows loop over 256-channel blocks.  g is a [B*N, ld] bf16 buffer, columns col0 .. col0+C.
-__global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const u16_t *__restrict__ g, int ld, int col0,
+// one wave per target (b, s); a half-wave (32 lanes x E channels) covers up to 32*E channels, wider
+// rows loop over blocks of that size.  g is a [B*N, ld] buffer, columns col0 .. col0+C.
+template <typename T>
+__global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const T *__restrict__ g, int ld, int col0,
                                                                    const float *__restrict__ w,
                                                                    const long *__restrict__ offsets,
                                                                    const int *__restrict__ entries, int N,
                                                                    int S, int C, int K,
-                                                                   u16_t *__restrict__ gfeat, long segments)
+                                                                   T *__restrict__ gfeat, long segments)
 {
+    constexpr int E = RowVec<T>::E;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5, hl = lane & 31;
     const long seg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seg >= segments) return;  // wave-uniform
     const long b = seg / S;
     const long beg = offsets[seg], end = offsets[seg + 1];
-    for (int c0 = 0; c0 < C; c0 += 256) {
-        const int c = c0 + hl * 8;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c0 = 0; c0 < C; c0 += 32 * E) {
+        const int c = c0 + hl * E;
+        float acc[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) acc[i] = 0.0f;
         for (long e = beg + half; e < end; e += 2) {
             const int ent = entries[e];
             const long n = ent / K;
             const float wt = w[(b * N + n) * K + (ent - (int)n * K)];
             if (c < C) {
-                float f[8];
-                unpack8f(*reinterpret_cast<const uint4 *>(g + (b * N + n) * (long)ld + col0 + c), f);
+                float f[E];
+                RowVec<T>::unpack(*reinterpret_cast<const uint4 *>(g + (b * N + n) * (long)ld + col0 + c), f);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(f[i], wt, acc[i]);
+                for (int i = 0; i < E; ++i) acc[i] = fmaf(f[i], wt, acc[i]);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], 32);
-        if (half == 0 && c < C) {
-            uint4 o;
-            o.x = pack2f(acc[0], acc[1]);
-            o.y = pack2f(acc[2], acc[3]);
-            o.z = pack2f(acc[4], acc[5]);
-            o.w = pack2f(acc[6], acc[7]);
-            *reinterpret_cast<uint4 *>(gfeat + seg * (long)C + c) = o;
-        }
+        for (int i = 0; i < E; ++i) acc[i] += __shfl_xor(acc[i], 32);
+        if (half == 0 && c < C)
+            *reinterpret_cast<uint4 *>(gfeat + seg * (long)C + c) = RowVec<T>::pack(acc);
     }
+}
+
+template <typename T>
+int interpolate_rows(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C, int k,
+                     void *out, int ld, int col0, float *out_w, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (!feat || !d2 || !idx || !out || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PCB_ERR_INVALID_ARG;
+    if (k < 1 || k > 4 || (C % E) || (ld % E) || (col0 % E) || col0 + C > ld) return PCB_ERR_INVALID_ARG;
+    const long nchunk = (long)B * N * (C / E);
+    const dim3 grid(grid_for((size_t)nchunk));
+    hipStream_t st = (hipStream_t)stream;
+    const T *f = (const T *)feat;
+    T *o = (T *)out;
+    switch (k) {
+        case 1: hipLaunchKernelGGL((interpolate_rows_kernel<T, 1>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
+        case 2: hipLaunchKernelGGL((interpolate_rows_kernel<T, 2>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
+        case 3: hipLaunchKernelGGL((interpolate_rows_kernel<T, 3>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
+        default: hipLaunchKernelGGL((interpolate_rows_kernel<T, 4>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
+    }
+    return pcb_check_launch();
+}
+
+template <typename T>
+int interpolate_bwd_csr(const void *grad_rows, int ld, int col0, const float *w, const long *offsets, const int *entries,
+                        int B, int N, int S, int C, int k, void *grad_feat, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (!grad_rows || !w || !offsets || !entries || !grad_feat || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PCB_ERR_INVALID_ARG;
+    if (k < 1 || (C % E) || (ld % E) || (col0 % E) || col0 + C > ld) return PCB_ERR_INVALID_ARG;
+    const long segments = (long)B * S;
+    hipLaunchKernelGGL(interpolate_bwd_csr_kernel<T>, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const T *)grad_rows, ld, col0, w, offsets, entries, N, S, C, k,
+                       (T *)grad_feat, segments);
+    return pcb_check_launch();
 }
 
 }  // namespace
@@ -332,20 +359,13 @@ __global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const u16_t *_
 extern "C" int pcb_interpolate_bf16(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S,
                                     int C, int k, void *out, int ld, int col0, float *out_w, void *stream)
 {
-    if (!feat || !d2 || !idx || !out || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PCB_ERR_INVALID_ARG;
-    if (k < 1 || k > 4 || (C & 7) || (ld & 7) || (col0 & 7) || col0 + C > ld) return PCB_ERR_INVALID_ARG;
-    const long nchunk = (long)B * N * (C >> 3);
-    const dim3 grid(grid_for((size_t)nchunk));
-    hipStream_t st = (hipStream_t)stream;
-    const u16_t *f = (const u16_t *)feat;
-    u16_t *o = (u16_t *)out;
-    switch (k) {
-        case 1: hipLaunchKernelGGL((interpolate_bf16_kernel<1>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
-        case 2: hipLaunchKernelGGL((interpolate_bf16_kernel<2>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
-        case 3: hipLaunchKernelGGL((interpolate_bf16_kernel<3>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
-        default: hipLaunchKernelGGL((interpolate_bf16_kernel<4>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
-    }
-    return pcb_check_launch();
+    return interpolate_rows<pcb_bf16>(feat, d2, idx, B, N, S, C, k, out, ld, col0, out_w, stream);
+}
+
+extern "C" int pcb_interpolate_rows_f32(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S,
+                                        int C, int k, void *out, int ld, int col0, float *out_w, void *stream)
+{
+    return interpolate_rows<float>(feat, d2, idx, B, N, S, C, k, out, ld, col0, out_w, stream);
 }
 
 extern "C" int pcb_interp_csr_count(const int64_t *idx, int B, int N, int S, int k, int *count, void *stream)
@@ -371,11 +391,12 @@ extern "C" int pcb_interpolate_bwd_csr_bf16(const void *grad_rows, int ld, int c
                                             const long *offsets, const int *entries, int B, int N, int S,
                                             int C, int k, void *grad_feat, void *stream)
 {
-    if (!grad_rows || !w || !offsets || !entries || !grad_feat || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PCB_ERR_INVALID_ARG;
-    if (k < 1 || (C & 7) || (ld & 7) || (col0 & 7) || col0 + C > ld) return PCB_ERR_INVALID_ARG;
-    const long segments = (long)B * S;
-    hipLaunchKernelGGL(interpolate_bwd_csr_kernel, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, (const u16_t *)grad_rows, ld, col0, w, offsets, entries, N, S, C, k,
-                       (u16_t *)grad_feat, segments);
-    return pcb_check_launch();
+    return interpolate_bwd_csr<pcb_bf16>(grad_rows, ld, col0, w, offsets, entries, B, N, S, C, k, grad_feat, stream);
+}
+
+extern "C" int pcb_interpolate_bwd_csr_f32(const void *grad_rows, int ld, int col0, const float *w,
+                                           const long *offsets, const int *entries, int B, int N, int S,
+                                           int C, int k, void *grad_feat, void *stream)
+{
+    return interpolate_bwd_csr<float>(grad_rows, ld, col0, w, offsets, entries, B, N, S, C, k, grad_feat, stream);
 }

@@ -9,6 +9,8 @@ space, rebuilt before every EdgeConv block) and the edge-feature gather run as g
 Activations are channels-last ([rows, C]) internally; the EdgeConv 1x1 convolutions are row GEMMs
 over the parameters of the stock nn.Conv2d / nn.BatchNorm2d sub-modules.  GPU only.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -78,11 +80,13 @@ class DGCNN(nn.Module):
             held.copy_(idx)
             ev = torch.cuda.Event()
             ev.record(side)
-        self._graph0 = ((xyz.data_ptr(), xyz._version, tuple(xyz.shape), k), held, ev)
+        # the weak reference pins the result to THIS tensor object: a later tensor that inherits the
+        # address of a dropped batch must not pick up its graph
+        self._graph0 = ((xyz.data_ptr(), xyz._version, tuple(xyz.shape), k), held, ev, weakref.ref(xyz))
 
     def _first_graph(self, xyz, x0, k):
         hit, self._graph0 = getattr(self, "_graph0", None), None
-        if hit is not None and hit[0] == (xyz.data_ptr(), xyz._version, tuple(xyz.shape), k):
+        if hit is not None and hit[3]() is xyz and hit[0] == (xyz.data_ptr(), xyz._version, tuple(xyz.shape), k):
             torch.cuda.current_stream().wait_event(hit[2])
             return hit[1]
         return None
@@ -93,7 +97,7 @@ class DGCNN(nn.Module):
         B, N, D = x.shape
         xf = x.float()
         if idx is None:
-            idx = ops.knn(xf, k)  # the graph is always built from fp32 distances
+            idx = ops.knn(xf.contiguous(), k)  # the graph is always built from fp32 distances
         if ((x.requires_grad or not torch.is_grad_enabled()) and D >= 32 and D % 8 == 0
                 and rowmlp.gathered_ok([block[0]], [block[1]])):
             # W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i: per-point products, gathered by the graph

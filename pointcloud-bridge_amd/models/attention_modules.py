@@ -24,6 +24,8 @@ The narrow (3..40 channel) layers stay fp32 in both precision modes: their 1x1 c
 them take 0.2-0.6 ms each), BatchNorm / ReLU / Sigmoid on them are ATen row ops.  The wide pointwise
 layers of GeometricFeatureExtraction go through ..rowmlp like the SA/FP stacks.  GPU only.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -146,7 +148,9 @@ class BridgeStructureEncoding(nn.Module):
                 h.copy_(r)
             ev = torch.cuda.Event()
             ev.record(side)
-        _geometry[self._geometry_key(xyz)] = (held[0], held[1], ev)
+        # pinned to THIS tensor object by a weak reference: a later tensor that inherits the address of
+        # a dropped batch must not pick up its neighbourhoods
+        _geometry[self._geometry_key(xyz)] = (held[0], held[1], ev, weakref.ref(xyz))
 
     def rows(self, xyz):
         """xyz [B,N,3] -> code rows [B*N, channels] (channels-last)."""
@@ -154,10 +158,12 @@ class BridgeStructureEncoding(nn.Module):
         xyz = xyz.float().contiguous()
         k = min(self.k, N)
         hit = _geometry.pop(self._geometry_key(xyz), None)
+        if hit is not None and hit[3]() is not xyz:
+            hit = None
         if hit is None:
             per_point, rel = self.geometry(xyz)
         else:
-            per_point, rel, ev = hit
+            per_point, rel, ev, _ = hit
             torch.cuda.current_stream().wait_event(ev)
         conv0, bn, _, conv1 = self.structure_mlp
         a = self.abs_pos_dim

@@ -97,7 +97,7 @@ class PointNet2(_SamplingPrefetchMixin, nn.Module):
 class MultiScaleFeatureFusion(nn.Module):
     """models/model.py:149-167: resample every decoder level to N points, 1x1 conv each, concatenate."""
 
-    coarse_rows = True  # bf16 mode: run each level's layer before the upsampling (see forward)
+    coarse_rows = True  # run each level's layer before the upsampling (see forward)
 
     def __init__(self, in_channels_list, out_channels):
         super().__init__()
@@ -117,7 +117,7 @@ class MultiScaleFeatureFusion(nn.Module):
             if S != n and n % S == 0 and (r & (r - 1)) == 0:
                 # scale = S/n = 2^-j is exact in fp32: nearest source of point i is i // r, i.e.
                 # every coarse row repeated r times (its backward is a plain sum over r rows)
-                if self.coarse_rows and rowmlp.is_bf16() and isinstance(conv[1], nn.BatchNorm1d) and not isinstance(conv[1], nn.SyncBatchNorm):
+                if self.coarse_rows and conv[0].out_channels % rowmlp.mode().q == 0:
                     # A pointwise layer commutes with the repetition, and batch statistics over
                     # rows repeated r times each equal those over the distinct rows: run the layer
                     # on the S coarse rows (r times less GEMM work, forward and backward) and

@@ -14,6 +14,8 @@ transposed views of channels-last storage.
 
 GPU only: CPU tensors raise (there is no fallback path).
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -63,6 +65,35 @@ def _key(xyz, npoint):
     return (xyz.data_ptr(), xyz._version, tuple(xyz.shape), int(npoint))
 
 
+# Parked results are looked up by the ADDRESS of the coordinate tensor they were computed from.  An
+# address alone can be inherited: if batch A is dropped without being forwarded (last step of an
+# epoch, an exception, eval starting), the caching allocator readily hands A's block to the next
+# tensor of the same shape -- which would then pick up A's samples and neighbours.  So every entry
+# also holds a weak reference to its level-0 tensor and is only served while that very tensor object
+# is the one asking (or, for the coarser levels, while it is still alive: their coordinate tensors
+# are owned by the entries themselves, so their addresses cannot be reused meanwhile).
+class _Source:
+    """Identity of the level-0 coordinate tensor a prefetch was issued for."""
+
+    def __init__(self, xyz):
+        self.ref = weakref.ref(xyz)
+        self.ptr = xyz.data_ptr()
+
+    def alive(self):
+        return self.ref() is not None
+
+    def matches(self, xyz):
+        """True unless `xyz` sits at the source's address without being the source."""
+        return xyz.data_ptr() != self.ptr or self.ref() is xyz
+
+
+def _drop_dead():
+    """Forget everything parked for coordinate tensors that no longer exist."""
+    for table in (_prefetched, _parked):
+        for k in [k for k, v in table.items() if not v[-1].alive()]:
+            del table[k]
+
+
 def side_stream(device):
     """The stream the coordinate-only work of the NEXT batch runs on (FPS pyramid here, the
     neighbourhood geometry of attention_modules.BridgeStructureEncoding)."""
@@ -92,6 +123,7 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
     side_stream(xyz.device)
     main = torch.cuda.current_stream()
     _side_stream.wait_stream(main)
+    src = _Source(xyz)
     _prefetched.clear()
     # entries of the batch in flight stay (a pipelined inference pass starts this prefetch before its
     # own decoder has taken its k-NN); their set of buffers is not the one written now
@@ -111,7 +143,7 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
             h.copy_(r)
         ev = torch.cuda.Event()
         ev.record(_side_stream)
-        _parked[key] = (held, ev, _parity)
+        _parked[key] = (held, ev, _parity, src)
 
     with torch.cuda.stream(_side_stream):
         for l, npoint in enumerate(npoints):
@@ -119,7 +151,7 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
             new_xyz = index_points(cur, idx)
             ev = torch.cuda.Event()
             ev.record(_side_stream)
-            _prefetched[_key(cur, npoint)] = (idx, new_xyz, ev)
+            _prefetched[_key(cur, npoint)] = (idx, new_xyz, ev, src)
             if balls is not None and balls[l] is not None:
                 radii, nsamples = balls[l]
                 park(_ball_key(radii, nsamples, cur, new_xyz), _ball_indices_now(radii, nsamples, cur, new_xyz))
@@ -128,8 +160,8 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
         for fine, coarse, k in (propagation or ()):
             nn_key = ("nn", levels[fine].data_ptr(), levels[coarse].data_ptr(), int(k))
             park(nn_key, ops.three_nn(levels[fine], levels[coarse], k))
-            if rowmlp.is_bf16() and torch.is_grad_enabled():
-                # the inverted index the interpolation's backward pass reduces over (bf16 engine)
+            if torch.is_grad_enabled():
+                # the inverted index the interpolation's backward pass reduces over
                 held_idx = _parked[nn_key][0][1]
                 park(("csr", held_idx.data_ptr()), rowmlp.build_interp_csr(held_idx, levels[coarse].shape[1]))
         ev = torch.cuda.Event()
@@ -204,11 +236,14 @@ def _sample(xyz, npoint):
         hit = _static.lookup(xyz, npoint)
         if hit is not None:
             return hit
-    hit = _prefetched.pop(_key(xyz, npoint), None)
+    hit = _prefetched.pop(_key(xyz, npoint), None) if _prefetched else None
+    if hit is not None and not (hit[3].alive() and hit[3].matches(xyz)):
+        _drop_dead()
+        hit = None
     if hit is None:
         idx = farthest_point_sample(xyz, npoint)
         return idx, index_points(xyz, idx)
-    idx, new_xyz, ev = hit
+    idx, new_xyz, ev, _ = hit
     main = torch.cuda.current_stream()
     main.wait_event(ev)
     idx.record_stream(main)
@@ -221,11 +256,16 @@ _owned = {}   # their storage: (kind, ordinal, parity) -> tensors, allocated onc
 _parity = 0
 
 
-def _take_parked(key):
+def _take_parked(key, xyz=None):
+    """The parked result for `key`, if its prefetch was issued for a coordinate tensor that is still
+    alive (and, when the key is built from `xyz`'s address, for that very tensor)."""
     hit = _parked.pop(key, None)
     if hit is None:
         return None
-    res, ev, _ = hit
+    res, ev, _, src = hit
+    if not src.alive() or (xyz is not None and not src.matches(xyz)):
+        _drop_dead()
+        return None
     torch.cuda.current_stream().wait_event(ev)
     return res
 
@@ -242,13 +282,13 @@ def _ball_indices_now(radii, nsamples, xyz, new_xyz):
 
 def _ball_indices(radii, nsamples, xyz, new_xyz):
     """Ball-query indices of every scale of a set abstraction: parked by prefetch_sampling or computed now."""
-    hit = _take_parked(_ball_key(radii, nsamples, xyz, new_xyz)) if _parked else None
+    hit = _take_parked(_ball_key(radii, nsamples, xyz, new_xyz), xyz) if _parked else None
     return hit if hit is not None else _ball_indices_now(radii, nsamples, xyz, new_xyz)
 
 
 def _nearest(xyz1, xyz2, k):
     """(d2, idx) of the k nearest xyz2 points of every xyz1 point: parked by prefetch_sampling or computed now."""
-    hit = _take_parked(("nn", xyz1.data_ptr(), xyz2.data_ptr(), int(k))) if _parked else None
+    hit = _take_parked(("nn", xyz1.data_ptr(), xyz2.data_ptr(), int(k)), xyz1) if _parked else None
     return hit if hit is not None else ops.three_nn(xyz1, xyz2, k)
 
 
@@ -308,7 +348,7 @@ def _grouped_mlp(convs, bns, xyz, new_xyz, feat, idx):
     """Grouping + shared MLP + max over the neighbours of one set-abstraction scale
     (reference :51-58 + :149-154 / :342-356) -> [B*S, C] rows.
 
-    bf16 mode with differentiable features of useful width: the first 1x1 conv is linear in
+    bf16 rows with differentiable features of useful width: the first 1x1 conv is linear in
     [x_j - c_s | f_j], so its feature part is evaluated per point (u = F Wf^T on N rows,
     rowmlp.point_linear) and the rows y0[s,j] = u[idx[s,j]] + Wx (x_j - c_s) are gathered
     (rowmlp.gathered_mlp; the coordinate difference is formed in fp32 as in the reference): the
@@ -404,7 +444,7 @@ def _propagate_rows(xyz1, xyz2, points1, points2, k):
     plus the column-layout code `perm` of rowmlp (0 = reference order)."""
     B, N, _ = xyz1.shape
     S, C = xyz2.shape[1], points2.shape[1]
-    if rowmlp.is_bf16() and S > 1 and C % 8 == 0:
+    if S > 1 and C % rowmlp.mode().q == 0:
         d2, idx = _nearest(xyz1, xyz2, k)
         csr = _take_parked(("csr", idx.data_ptr())) if _parked else None
         skip = None if points1 is None else _channels_last(points1).reshape(B * N, -1)

@@ -67,7 +67,7 @@ class _NeighbourMLP(torch.autograd.Function):
                     dw2p.data_ptr())
             _launch("pcb_bn_bwd_finalize", C, sums.data_ptr(), parts, P * k, C, consts[0].data_ptr(),
                     consts[2].data_ptr(), consts[3].data_ptr(), training, pq[0].data_ptr(), pq[1].data_ptr(),
-                    pq[2].data_ptr(), pq[3].data_ptr(), 0)
+                    pq[2].data_ptr(), pq[3].data_ptr(), 0, 0)
             _launch("pcb_nbr_mlp_backward_apply", P * k * C * C, base.data_ptr(), rel.data_ptr(), P, k, C,
                     wr.data_ptr(), consts[0].data_ptr(), consts[1].data_ptr(), pq[0].data_ptr(), pq[1].data_ptr(),
                     w2.data_ptr(), g.data_ptr(), arg.data_ptr(), dbase.data_ptr(), dwrp.data_ptr())

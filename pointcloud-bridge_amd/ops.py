@@ -96,13 +96,17 @@ def apply_concurrency_hint():
         _hint_now = want
 
 
-def _launch(name, units, *args):
+def _launch(name, units, *args, check=None):
     """Call entry point `name` of libpcb_hip.so on the current stream; raise on a bad status.
-    (`units` documents the call's work at the call site; timing lives in the library.)"""
+    (`units` documents the call's work at the call site; timing lives in the library.)
+    check: called after the foreign call returns -- re-raises what a host callback of the call caught
+    (an exception must not unwind through the C frames)."""
     fn = _entry.get(name)
     if fn is None or _lib._lib is None:  # first use, or the library handle was dropped: (re)load, fail loudly
         fn = _entry[name] = getattr(_lib.load(), name)
     status = fn(*args, torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    if check is not None:
+        check()
     if status:
         _lib.check(status, name)
 

@@ -49,8 +49,9 @@ class FlatGradAllReduce:
     """Averages the gradients of `params` across ranks with a single all-reduce.
 
     zero() drops the gradients (backward then writes fresh tensors: no accumulate kernels);
-    reduce() packs them into ONE flat fp32 buffer with one concatenation, all-reduces it once and
-    hands each parameter a view of the averaged buffer.  With a single rank both are no-ops."""
+    reduce() packs them into ONE flat fp32 buffer with one concatenation (every parameter, zeros for
+    a missing gradient: identical layout on every rank), all-reduces it once and hands each parameter
+    a view of the averaged buffer.  With a single rank only the packing happens."""
 
     def __init__(self, params, group=None, keep_grad_tensors=False, assign_views=True):
         self.params = [p for p in params if p.requires_grad]
@@ -72,28 +73,35 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = None
 
+    def pack(self):
+        """One flat fp32 tensor of ALL parameters' gradients in parameter order -- zeros where a
+        parameter has none this step, so every rank packs the same layout whatever branch it took."""
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+
     def reduce(self):
-        """Sum over ranks, divide by the world size (mean, as DDP does).  No-op for one rank."""
+        """Sum over ranks, divide by the world size (mean, as DDP does).  With one rank: .flat is just
+        the packed gradient (no collective), so callers need no special case."""
+        self.flat = self.pack()
         if self.world == 1:
             return
-        live = [p for p in self.params if p.grad is not None]
-        self.flat = torch.cat([p.grad.reshape(-1) for p in live])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(self.world)
         if not self.assign_views:
-            if len(live) != len(self.params):
-                raise RuntimeError("FlatGradAllReduce: a parameter has no gradient (flat layout would shift)")
             return
         off = 0
         views = []
-        for p in live:
+        for p in self.params:
             n = p.numel()
             views.append(self.flat[off:off + n].view_as(p))
             off += n
         if self.keep:
-            torch._foreach_copy_([p.grad for p in live], views)
+            live = [(p.grad, v) for p, v in zip(self.params, views) if p.grad is not None]
+            torch._foreach_copy_([a for a, _ in live], [b for _, b in live])
+            for p, v in zip(self.params, views):
+                if p.grad is None:
+                    p.grad = v.clone()
         else:
-            for p, v in zip(live, views):
+            for p, v in zip(self.params, views):
                 p.grad = v
 
 
@@ -137,6 +145,10 @@ class FlatAdam:
         if flat_grad.numel() != self.flat.numel():
             raise ValueError("flat gradient does not match the parameters")
         self.step_t += 1
+        # the parameters are views of self.flat: this update bumps no version counter of theirs, so the
+        # eval-mode operand cache of the MLP engine is told explicitly
+        from . import rowmlp
+        rowmlp.note_parameter_update()
         torch._fused_adam_([self.flat], [flat_grad], [self.exp_avg], [self.exp_avg_sq], [], [self.step_t],
                            lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], weight_decay=self.weight_decay,
                            eps=self.eps, amsgrad=False, maximize=False)

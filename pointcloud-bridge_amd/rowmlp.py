@@ -2,23 +2,29 @@
 the neighbour axis], the block the reference repeats in every SetAbstraction / FeaturePropagation /
 EdgeConv layer (models/pointnet2_utils.py:149-154, :207-209, :353-356; models/DGCNN.py:134-148).
 
-Two numerically distinct execution modes, selected with `set_precision`:
+ONE engine, two row types, selected with `set_precision`:
 
-  "fp32"  (default)  torch row GEMM + ATen BatchNorm on fp32 rows.  This is the parity mode: network
-                     logits stay within 1e-4 relative of the reference (tests/test_gpu_modules.py).
-  "bf16"             bf16 activations / fp32 statistics and master weights.  Per layer only the
-                     pre-BatchNorm GEMM output is kept; statistics, normalisation, activation,
-                     pooling and the BatchNorm backward are hand-written gfx950 kernels
-                     (csrc/rowbn.hip through the C ABI).  This is the throughput mode bench.py runs
-                     (BASELINE.json config 2 names bf16).
+  "fp32"  (default)  fp32 rows on the exact fp32 matrix cores (csrc/gemm_f32.hip).  The parity mode:
+                     network logits stay within 1e-4 relative of the reference
+                     (tests/test_gpu_modules.py).  No library GEMM, no ATen BatchNorm.
+  "bf16"             bf16 rows / fp32 statistics and master weights (csrc/gemm.hip).  The throughput
+                     mode bench.py runs (BASELINE.json config 2 names bf16).
 
-Both modes read the parameters of the caller's stock nn.Conv*/nn.BatchNorm* modules and keep their
-running statistics exactly as nn.BatchNorm does, so state_dicts stay interchangeable.
+In both, a layer keeps only its pre-BatchNorm GEMM output; the BatchNorm / activation algebra of the
+neighbouring layers is applied while the next GEMM loads its operand, batch statistics and the
+BatchNorm-backward sums come out of GEMM epilogues, and a whole stack is enqueued by one native call
+per direction (csrc/stack.hip).  The host code below is the same for both modes -- only the dtype
+and the padding quantum (16 bytes = 8 bf16 or 4 fp32 columns) differ.
+
+The parameters live in the caller's stock nn.Conv*/nn.BatchNorm* modules and their running
+statistics are kept exactly as nn.BatchNorm does, so state_dicts stay interchangeable.
+nn.SyncBatchNorm layers all-reduce their statistics over the process group (parallel.py).
 """
 import ctypes
 import weakref
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -27,22 +33,25 @@ from .ops import _launch, apply_concurrency_hint, on_device
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 _PRECISION = "fp32"
-# bf16 engine: "fused" = own MFMA GEMMs with fused BatchNorm algebra (csrc/gemm.hip);
-# "staged" = hipBLASLt GEMMs (torch.mm) + the row kernels of csrc/rowbn.hip (kept for A/B timing)
-_ENGINE = "fused"
 
 
-def set_engine(name):
-    global _ENGINE
-    if name not in ("fused", "staged"):
-        raise ValueError(name)
-    _ENGINE = name
+class _Mode:
+    """Row type of the engine: torch dtype, columns per 16-byte chunk, entry-point suffix, pcb_dtype."""
+
+    def __init__(self, dtype, quantum, suffix, code):
+        self.dtype, self.q, self.sfx, self.code = dtype, quantum, suffix, code
+
+    def pad(self, k):
+        return (k + self.q - 1) // self.q * self.q
+
+
+_MODES = {"bf16": _Mode(torch.bfloat16, 8, "bf16", 0), "fp32": _Mode(torch.float32, 4, "f32", 1)}
 
 
 def set_precision(mode):
-    """'fp32' (parity mode) or 'bf16' (fused bf16 row kernels)."""
+    """'fp32' (parity mode) or 'bf16' (throughput mode) rows for the fused MLP engine."""
     global _PRECISION
-    if mode not in ("fp32", "bf16"):
+    if mode not in _MODES:
         raise ValueError(f"precision must be 'fp32' or 'bf16', got {mode!r}")
     _PRECISION = mode
 
@@ -53,6 +62,15 @@ def get_precision():
 
 def is_bf16():
     return _PRECISION == "bf16"
+
+
+def mode():
+    return _MODES[_PRECISION]
+
+
+def pad_cols(k):
+    """k rounded up to the current row type's 16-byte chunk (8 bf16 / 4 fp32 columns)."""
+    return mode().pad(k)
 
 
 def pad8(k):
@@ -71,11 +89,10 @@ def _weight2d(conv):
     return conv.weight.view(conv.out_channels, conv.in_channels)
 
 
-# ---------------------------------------------------------------------------------------------
-# fp32 parity mode
-# ---------------------------------------------------------------------------------------------
 def _bn_rows_fp32(bn, x):
-    """BatchNorm1d/2d over rows [rows, C] with the module's exact running-stat bookkeeping."""
+    """ATen BatchNorm over rows [rows, C] with the module's exact running-stat bookkeeping -- only for
+    layers the engine does not take (channel counts that are not multiples of 4: the 3..13-channel
+    layers of the bridge encoders, models/attention_modules.py)."""
     if isinstance(bn, nn.SyncBatchNorm):
         return bn(x)  # statistics all-reduced over the process group (parallel.sync_batchnorm)
     eaf = 0.0 if bn.momentum is None else bn.momentum
@@ -90,121 +107,28 @@ def _bn_rows_fp32(bn, x):
         bn.weight, bn.bias, use_batch, eaf, bn.eps)
 
 
-# ---------------------------------------------------------------------------------------------
-# bf16 mode
-# ---------------------------------------------------------------------------------------------
-def _mm_f32out(a, b):
-    """a @ b with bf16 operands and an fp32 result (weight gradients keep fp32 precision)."""
-    try:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    except (TypeError, RuntimeError):
-        return torch.mm(a, b).float()
-
-
-class _LinearBNAct(torch.autograd.Function):
-    """x [R,Kp] bf16 -> act(BN(x @ W^T)) as rows [R,C] bf16, or pooled over `pool` consecutive rows
-    ([R/pool, C] bf16).  Saves x, the bf16 GEMM output y and the per-channel statistics only."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
-                act, pool, perm):
-        R, Kp = x.shape
-        C = weight.shape[0]
-        dev = x.device
-        wp = padded_weight_from(weight, Kp, perm)
-        y = torch.mm(x, wp.t())
-        stats = torch.zeros(6, C, dtype=torch.float32, device=dev)  # sums(2) | scale | shift | mean | invstd
-        sums, scale, shift, mean, invstd = stats[0:2], stats[2], stats[3], stats[4], stats[5]
-        with on_device(dev):
-            if training:
-                _launch("pcb_colstats_bf16", R * C, y.data_ptr(), R, C, sums.data_ptr())
-            _launch("pcb_bn_finalize", C, sums.data_ptr(), 1, R, 0, C,
-                    0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
-                    0 if bias is None else bias.data_ptr(),
-                    0 if running_mean is None else running_mean.data_ptr(),
-                    0 if running_var is None else running_var.data_ptr(),
-                    float(momentum), float(eps), int(training), scale.data_ptr(), shift.data_ptr(),
-                    mean.data_ptr(), invstd.data_ptr(), 0)
-            if pool:
-                G = R // pool
-                out = torch.empty(G, C, dtype=torch.bfloat16, device=dev)
-                arg = torch.empty(G, C, dtype=torch.uint8, device=dev)
-                _launch("pcb_bn_act_max_bf16", R * C, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), G,
-                        pool, C, act, out.data_ptr(), arg.data_ptr())
-            else:
-                arg = None
-                out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-                _launch("pcb_bn_act_bf16", R * C, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), R, C, act,
-                        out.data_ptr())
-        ctx.save_for_backward(x, wp, y, stats, arg)
-        ctx.cfg = (int(training), act, pool, perm, weight.shape, bias is not None, gamma is not None)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        x, wp, y, stats, arg = ctx.saved_tensors
-        training, act, pool, perm, wshape, has_bias, has_affine = ctx.cfg
-        R, Kp = x.shape
-        C = wp.shape[0]
-        dev = x.device
-        scale, shift, mean, invstd = stats[2], stats[3], stats[4], stats[5]
-        bsums = torch.zeros(2, C, dtype=torch.float32, device=dev)
-        dy = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-        with on_device(dev):
-            if pool:
-                g32 = g.float().contiguous()
-                _launch("pcb_bn_act_max_bwd_bf16", R * C, g32.data_ptr(), arg.data_ptr(), y.data_ptr(),
-                        scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R // pool,
-                        pool, C, act, training, bsums.data_ptr(), dy.data_ptr())
-            else:
-                gb = g.to(torch.bfloat16).contiguous()
-                _launch("pcb_bn_act_bwd_bf16", R * C, gb.data_ptr(), y.data_ptr(), scale.data_ptr(),
-                        shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), R, C, act, training,
-                        bsums.data_ptr(), dy.data_ptr())
-        dx = torch.mm(dy, wp) if ctx.needs_input_grad[0] else None
-        dwp = _mm_f32out(dy.t(), x)  # [C, Kp]
-        cout, k = wshape[0], wshape[1]
-        dw = _unpad_weight_grad(dwp, k, perm).reshape(wshape)
-        # d(bias): sum of dy over rows -- exactly zero under batch statistics, scale*s1 otherwise
-        dbias = None
-        if has_bias:
-            dbias = torch.zeros(C, dtype=torch.float32, device=dev) if training else scale * bsums[0]
-        dgamma = bsums[1].clone() if has_affine else None
-        dbeta = bsums[0].clone() if has_affine else None
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
-
-
-def padded_weight_from(weight, kp, perm):
-    """[Cout, kp] bf16 copy of a 1x1 conv weight ([Cout, K] or [Cout, K, 1(,1)]) in the column
-    layout of the bf16 row buffer it multiplies:
+def padded_weight_from(weight, kp, perm, quantum=8):
+    """[Cout, kp] copy (bf16 for quantum 8, fp32 for 4) of a 1x1 conv weight ([Cout, K] or
+    [Cout, K, 1(,1)]) in the column layout of the row buffer it multiplies -- the host statement of what
+    pcb_prep_weights_* builds (tests compare the two):
       perm == 0  reference order, zero padded to kp
-      perm = C > 0   grouped rows of pcb_group_rows_bf16: the C feature columns first, then the 3
+      perm = C > 0   grouped rows of pcb_group_rows_*: the C feature columns first, then the 3
                  centred coordinates (reference: coordinates first, :56/:347)
       perm = -D < 0  interpolate+concat rows of interpolate_concat: the first D (skip) columns stay
-                 in place, the rest start at column pad8(D)"""
+                 in place, the rest start at column pad(D)"""
     w = weight.reshape(weight.shape[0], -1)
     cout, k = w.shape
-    wp = torch.zeros(cout, kp, dtype=torch.bfloat16, device=w.device)
+    wp = torch.zeros(cout, kp, dtype=torch.bfloat16 if quantum == 8 else torch.float32, device=w.device)
     if perm > 0:
         wp[:, :perm] = w[:, 3:3 + perm]
         wp[:, perm:perm + 3] = w[:, :3]
     elif perm < 0:
-        d, dp = -perm, pad8(-perm)
+        d, dp = -perm, (-perm + quantum - 1) // quantum * quantum
         wp[:, :d] = w[:, :d]
         wp[:, dp:dp + k - d] = w[:, d:]
     else:
         wp[:, :k] = w
     return wp
-
-
-def _unpad_weight_grad(dwp, k, perm):
-    """Inverse of padded_weight_from's column layout for the weight gradient [Cout, kp] -> [Cout, k]."""
-    if perm > 0:
-        return torch.cat([dwp[:, perm:perm + 3], dwp[:, :perm]], dim=1)
-    if perm < 0:
-        d, dp = -perm, pad8(-perm)
-        return torch.cat([dwp[:, :d], dwp[:, dp:dp + k - d]], dim=1)
-    return dwp[:, :k]
 
 
 def _counter(bn):
@@ -225,26 +149,39 @@ def _bn_bookkeeping(bn):
     return eaf
 
 
-def _rows_bf16(x, kp):
-    """Make x [R,K] a contiguous bf16 [R,kp] operand (zero padded on the right)."""
-    x = x.to(torch.bfloat16)
+def _rows(x, kp, m):
+    """Make x [R,K] a contiguous [R,kp] operand of row type m (zero padded on the right)."""
+    x = x.to(m.dtype)
     if x.shape[1] == kp:
         return x.contiguous()
     return F.pad(x, (0, kp - x.shape[1]))
 
 
-# Inference with constant weights: the bf16 operands and the eval-mode BatchNorm constants of a stack
-# depend on parameters and running statistics only, so a no-grad eval-mode call keeps them (keyed by the
-# first weight tensor, validated by every tensor's version counter) and the next call skips their
-# preparation (23 + 34 launches of a PN2-MSG forward pass).
+# ---------------------------------------------------------------------------------------------
+# Inference with constant weights: the prepared operands and the eval-mode BatchNorm constants of a
+# stack depend on parameters and running statistics only, so a no-grad eval-mode call keeps them and
+# the next call skips their preparation (23 + 34 launches of a PN2-MSG forward pass).
+# Validation: every tensor's version counter (optimizer steps through torch.optim, load_state_dict,
+# in-place edits), the first tensor's identity and address, AND a process-wide generation counter for
+# the updates that bypass version counters: parallel.FlatAdam steps one flat buffer the parameters
+# are views of, and the library updates running statistics through raw pointers in every
+# training-mode forward.  Both call note_parameter_update().
+# ---------------------------------------------------------------------------------------------
 _eval_operands = {}
+_generation = 0
+
+
+def note_parameter_update():
+    """Invalidate the eval-mode operand cache: parameters or running statistics were updated by a path
+    that does not bump tensor version counters (a flat-buffer optimizer step, a library-side
+    running-statistics update)."""
+    global _generation
+    _generation += 1
 
 
 def _eval_lookup(layers, first, extra):
-    """(key, versions, (wbuf, stz) or None) for a no-grad call whose layers are all in eval mode."""
-    # version counters catch in-place updates (optimizer steps, load_state_dict, running statistics);
-    # the first tensor's identity (weak reference below) and address catch a replaced module
-    versions = tuple([t._version for lay in layers for t in lay[:6] if t is not None]) + (first.data_ptr(),)
+    """(key, versions, cached buffers or None) for a no-grad call whose layers are all in eval mode."""
+    versions = tuple([t._version for lay in layers for t in lay[:6] if t is not None]) + (first.data_ptr(), _generation)
     key = (id(first),) + extra
     hit = _eval_operands.get(key)
     if hit is not None and hit[0]() is first and hit[1] == versions:
@@ -258,21 +195,87 @@ def _eval_store(key, first, versions, bufs):
     _eval_operands[key] = (weakref.ref(first), versions, bufs)
 
 
-class _FusedStack(torch.autograd.Function):
-    """A stack of L layers act(BN(. W^T)) on bf16 rows with everything between the GEMMs fused
-    (csrc/gemm.hip): layer l's BatchNorm+activation is applied while layer l+1 loads its operand,
-    batch statistics come out of the GEMM epilogue, the backward recomputes dy on load.  Per layer
-    only y_l = x_l W_l^T is stored.  The last layer's activation is materialised (rows) or
-    max-pooled over `pool` consecutive rows.
+# ---------------------------------------------------------------------------------------------
+# SyncBatchNorm: the library hands the local statistics totals (2C floats per layer) to this callback
+# between launches; it all-reduces them over the layer's process group in stream order.
+# ---------------------------------------------------------------------------------------------
+_SYNC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 
-    Flat argument list: x, act, pool, perm, stat_repeat, L, then per layer
+
+class _SyncStruct(ctypes.Structure):
+    _fields_ = [("allreduce", _SYNC_FN), ("ctx", ctypes.c_void_p), ("global_rows", ctypes.c_long)]
+
+
+class _Sync:
+    """pcb_sync for one stack call: owns the ctypes callback and finds the torch tensor behind the
+    device pointer the library passes (it always lies inside one of the call's float buffers)."""
+
+    def __init__(self, group, rows, buffers):
+        self.group = group
+        self.buffers = buffers
+        self.error = None
+        self._cb = _SYNC_FN(self._allreduce)
+        world = dist.get_world_size(group)
+        self.struct = _SyncStruct(self._cb, None, int(rows) * world)  # every rank holds the same number of rows
+
+    def _allreduce(self, ptr, n, _ctx):
+        try:
+            for t in self.buffers:
+                base = t.data_ptr()
+                if base <= ptr < base + t.numel() * 4:
+                    off = (ptr - base) // 4
+                    dist.all_reduce(t.view(-1)[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
+                    return 0
+            raise RuntimeError("SyncBatchNorm: statistics pointer outside the stack's buffers")
+        except BaseException as e:  # an exception must not unwind through the C frames
+            self.error = e
+            return -1
+
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+    def check(self):
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise err
+
+
+def _sync_group(bns):
+    """The process group to synchronise over if these layers are training-mode SyncBatchNorm under an
+    initialised process group of more than one rank; else None.  (False, None) = no sync."""
+    sync = [bn for bn in bns if isinstance(bn, nn.SyncBatchNorm)]
+    if not sync or not any(bn.training for bn in sync):
+        return False, None
+    if not dist.is_available() or not dist.is_initialized():
+        return False, None
+    group = getattr(sync[0], "process_group", None)
+    if dist.get_world_size(group) == 1:
+        return False, None
+    if len(sync) != len(bns):
+        raise NotImplementedError("a stack mixes SyncBatchNorm and BatchNorm layers")
+    return True, group
+
+
+_MAX_PARTS = 768     # slabs a gemm_nt launch writes at most (PCB_MAX_SLABS)
+_GATHER_PARTS = 1024  # a gathered first layer
+
+
+class _FusedStack(torch.autograd.Function):
+    """A stack of L layers act(BN(. W^T)) on rows with everything between the GEMMs fused
+    (csrc/gemm.hip, csrc/gemm_f32.hip): layer l's BatchNorm+activation is applied while layer l+1
+    loads its operand, batch statistics come out of the GEMM epilogue, the backward recomputes dy on
+    load.  Per layer only y_l = x_l W_l^T is stored.  The last layer's activation is materialised
+    (rows) or max-pooled over `pool` consecutive rows.
+
+    Flat argument list: x, act, pool, perm, stat_repeat, L, mode, sync group (or False), then per layer
     (weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
     num_batches_tracked or None -- incremented by the finalize kernel)."""
 
     NPER = 10
+    NHEAD = 8
 
     @staticmethod
-    def forward(ctx, x, act, pool, perm, stat_repeat, L, *flat):
+    def forward(ctx, x, act, pool, perm, stat_repeat, L, m, group, *flat):
         dev = x.device
         R, Kp = x.shape
         layers = [flat[i * _FusedStack.NPER:(i + 1) * _FusedStack.NPER] for i in range(L)]
@@ -280,43 +283,49 @@ class _FusedStack(torch.autograd.Function):
         widths = [t[0].shape[0] for t in layers]
         lib = _lib.load()
         # caller-owned buffers of pcb_mlp_stack_forward/backward (include/pcb_hip.h)
-        ybuf = torch.empty(R * sum(widths), dtype=torch.bfloat16, device=dev)
+        ybuf = torch.empty(R * sum(widths), dtype=m.dtype, device=dev)
         stz = torch.empty(10 * sum(widths), dtype=torch.float32, device=dev)
         parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
-        desc = _stack_desc(layers, widths, ybuf, R)
+        desc = _stack_desc(layers, widths, ybuf, R, m)
         ready = 0
         cache_key = None
+        training = any(t[6] for t in layers)
         # pipelined inference: the next batch's FPS may be running beside this pass; training: a hint left
         # over from the backward pass is dropped once its event has completed
         apply_concurrency_hint()
-        if not torch.is_grad_enabled() and not any(t[6] for t in layers):
-            cache_key, versions, hit = _eval_lookup(layers, layers[0][0], ("stack", Kp, perm, L))
+        if not torch.is_grad_enabled() and not training:
+            cache_key, versions, hit = _eval_lookup(layers, layers[0][0], ("stack", Kp, perm, L, m.code))
             if hit is not None:
                 wbuf, stz = hit
                 ready = 2
+        if training:
+            note_parameter_update()  # running statistics change under the eval cache's feet
         if not ready:
-            wbuf = torch.empty(lib.pcb_mlp_stack_wbuf_elems(L, desc, Kp, int(need_dx)), dtype=torch.bfloat16, device=dev)
+            wbuf = torch.empty(lib.pcb_mlp_stack_wbuf_elems(L, desc, Kp, int(need_dx)), dtype=m.dtype, device=dev)
         fdesc = (ctypes.c_double * (2 * L))(*[float(v) for t in layers for v in (t[7], t[8])])
         C = widths[-1]
         if pool:
-            out = torch.empty(R // pool, C, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(R // pool, C, dtype=m.dtype, device=dev)
             arg = torch.empty(R // pool, C, dtype=torch.uint8, device=dev)
         else:
-            out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(R, C, dtype=m.dtype, device=dev)
             arg = None
+        sync = _Sync(group, R, (stz, parts)) if group is not False else None
         with on_device(dev):
-            _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, x.data_ptr(), R, Kp, perm, act, pool, int(need_dx) | ready,
-                    int(stat_repeat), 0, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
-                    0 if arg is None else arg.data_ptr())
+            _launch("pcb_mlp_stack_forward", 0, m.code, L, desc, fdesc, x.data_ptr(), R, Kp, perm, act, pool,
+                    int(need_dx) | ready, int(stat_repeat), 0, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(),
+                    _MAX_PARTS, None if sync is None else sync.ref(), out.data_ptr(),
+                    0 if arg is None else arg.data_ptr(), check=(None if sync is None else sync.check))
         if cache_key is not None and not ready:
             _eval_store(cache_key, layers[0][0], versions, (wbuf, stz))
         ctx.save_for_backward(x, arg, ybuf, stz, wbuf, *[t[0] for t in layers])
-        ctx.cfg = (act, pool, perm, L, need_dx, [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
+        ctx.cfg = (act, pool, perm, L, need_dx, m, group,
+                   [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
         return out
 
     @staticmethod
     def backward(ctx, g):
-        act, pool, perm, L, need_dx, flags = ctx.cfg
+        act, pool, perm, L, need_dx, m, group, flags = ctx.cfg
         saved = ctx.saved_tensors
         x, arg, ybuf, stz, wbuf = saved[:5]
         weights = saved[5:5 + L]
@@ -324,7 +333,8 @@ class _FusedStack(torch.autograd.Function):
         dev = x.device
         R, Kp = x.shape
         lib = _lib.load()
-        g = g.float().contiguous() if pool else g.to(torch.bfloat16).contiguous()
+        g = g.float().contiguous() if pool else g.to(m.dtype).contiguous()
+        H = _FusedStack.NHEAD
         grads = [None] * (L * _FusedStack.NPER)
         outs = []
         kp, ws_elems = Kp, 0
@@ -332,7 +342,7 @@ class _FusedStack(torch.autograd.Function):
             C = widths[l]
             has_bias, has_affine, _ = flags[l]
             base = l * _FusedStack.NPER
-            dw = grads[base + 0] = torch.empty_like(w) if ctx.needs_input_grad[6 + base] else None
+            dw = grads[base + 0] = torch.empty_like(w) if ctx.needs_input_grad[H + base] else None
             dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev) if has_bias else None
             dgamma = grads[base + 2] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
             dbeta = grads[base + 3] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
@@ -341,20 +351,22 @@ class _FusedStack(torch.autograd.Function):
                 ws_elems += lib.pcb_gemm_tn_workspace(R, C, kp)  # one slab region per layer
             kp = C
         layers = [(w, None, None, None, None, None, flags[l][2]) for l, w in enumerate(weights)]
-        desc = _stack_desc(layers, widths, ybuf, R, outs)
+        desc = _stack_desc(layers, widths, ybuf, R, m, outs)
         want_dx = bool(ctx.needs_input_grad[0]) and need_dx
-        dx = torch.empty(R, Kp, dtype=torch.bfloat16, device=dev) if want_dx else None
+        dx = torch.empty(R, Kp, dtype=m.dtype, device=dev) if want_dx else None
         maxw = max([Kp] + widths[:-1])
-        dzbuf = torch.empty(2 * R * maxw, dtype=torch.bfloat16, device=dev) if L > 1 else None
-        parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
+        dzbuf = torch.empty(2 * R * maxw, dtype=m.dtype, device=dev) if L > 1 else None
+        parts = torch.empty(_MAX_PARTS * 2 * max(widths + [Kp]), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
+        sync = _Sync(group, R, (stz, parts)) if group is not False else None
         apply_concurrency_hint()
         with on_device(dev):
-            _launch("pcb_mlp_stack_backward", 0, L, desc, x.data_ptr(), g.data_ptr(),
+            _launch("pcb_mlp_stack_backward", 0, m.code, L, desc, x.data_ptr(), g.data_ptr(),
                     0 if arg is None else arg.data_ptr(), R, Kp, perm, act, pool, int(need_dx), 0, wbuf.data_ptr(),
-                    stz.data_ptr(), parts.data_ptr(), ws.data_ptr(), 0 if dzbuf is None else dzbuf.data_ptr(),
-                    0 if dx is None else dx.data_ptr())
-        return (dx, None, None, None, None, None, *grads)
+                    stz.data_ptr(), parts.data_ptr(), _MAX_PARTS, None if sync is None else sync.ref(), ws.data_ptr(),
+                    0 if dzbuf is None else dzbuf.data_ptr(), 0 if dx is None else dx.data_ptr(),
+                    check=(None if sync is None else sync.check))
+        return (dx, None, None, None, None, None, None, None, *grads)
 
 
 class _PointLinear(torch.autograd.Function):
@@ -397,7 +409,7 @@ class _PointLinear(torch.autograd.Function):
             if ctx.needs_input_grad[0] and wt is not None:
                 dx = torch.empty(n, K, dtype=torch.bfloat16, device=dev)
                 _launch("pcb_gemm_nt_bf16", 2 * n * (C + K), 0, gb.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 0, 0, wt.data_ptr(), n, K,
-                        C, dx.data_ptr(), 0)
+                        C, dx.data_ptr(), 0, 0)
         return dx, dw
 
 
@@ -411,8 +423,8 @@ class _GatheredStack(torch.autograd.Function):
     y0[(s,j)] = u[idx[s,j]] + v[s] + wx (xyz[idx[s,j]] - ctr[s]) with per-point products u [B*N,C0],
     v [B*S,C0] (fp32, from point_linear; v optional) and, optionally, the coordinate columns wx
     [C0,3] of the first conv applied to the fp32 difference exactly as the reference forms it; then
-    BatchNorm + activation and the remaining layers / pooling exactly as _FusedStack.  Backward
-    returns du, dv, dwx; autograd takes du, dv on through the caller's point_linear calls.
+    BatchNorm + activation and the remaining layers / pooling exactly as _FusedStack (bf16 rows).
+    Backward returns du, dv, dwx; autograd takes du, dv on through the caller's point_linear calls.
 
     Flat argument list: u, v, wx, xyz, ctr, idx, ns, act, pool, L, then per layer (weight, bias,
     gamma, beta, running_mean, running_var, training, momentum, eps, num_batches_tracked or None);
@@ -424,6 +436,7 @@ class _GatheredStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, v, wx, xyz, ctr, idx, ns, act, pool, L, *flat):
         dev = u.device
+        m = _MODES["bf16"]
         B, S = idx.shape[0], idx.shape[1]
         N = u.shape[0] // B
         R = B * S * ns
@@ -432,16 +445,19 @@ class _GatheredStack(torch.autograd.Function):
         lib = _lib.load()
         ybuf = torch.empty(R * sum(widths), dtype=torch.bfloat16, device=dev)
         stz = torch.empty(10 * sum(widths), dtype=torch.float32, device=dev)
-        parts = torch.empty(max(_MAX_PARTS, 1024) * 2 * max(widths), dtype=torch.float32, device=dev)
-        desc = _stack_desc(layers, widths, ybuf, R)
+        parts = torch.empty(_GATHER_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
+        desc = _stack_desc(layers, widths, ybuf, R, m)
         ready = 0
         cache_key = None
-        if not torch.is_grad_enabled() and not any(t[6] for t in layers):
+        training = any(t[6] for t in layers)
+        if not torch.is_grad_enabled() and not training:
             first = next(t for lay in layers for t in lay[:6] if t is not None)
             cache_key, versions, hit = _eval_lookup(layers, first, ("gathered", L))
             if hit is not None:
                 wbuf, stz = hit
                 ready = 2
+        if training:
+            note_parameter_update()
         if not ready:
             nw = lib.pcb_mlp_stack_wbuf_elems(L, desc, 0, 0)
             wbuf = torch.empty(max(nw, 1), dtype=torch.bfloat16, device=dev)
@@ -458,8 +474,8 @@ class _GatheredStack(torch.autograd.Function):
             out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
             arg = None
         with on_device(dev):
-            _launch("pcb_mlp_stack_forward", 0, L, desc, fdesc, 0, R, 0, 0, act, pool, ready, 1, gather,
-                    wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), out.data_ptr(),
+            _launch("pcb_mlp_stack_forward", 0, m.code, L, desc, fdesc, 0, R, 0, 0, act, pool, ready, 1, gather,
+                    wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), _GATHER_PARTS, None, out.data_ptr(),
                     0 if arg is None else arg.data_ptr())
         if cache_key is not None and not ready:
             _eval_store(cache_key, first, versions, (wbuf, stz))
@@ -472,6 +488,7 @@ class _GatheredStack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         act, pool, L, ns, B, N, S, widths, has_v, has_wx, flags = ctx.cfg
+        m = _MODES["bf16"]
         saved = ctx.saved_tensors
         idx, arg, ybuf, stz, wbuf, xyz, ctr = saved[:7]
         weights = [None] + list(saved[7:7 + L - 1])
@@ -495,7 +512,7 @@ class _GatheredStack(torch.autograd.Function):
             dbeta = grads[base + 3] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
             outs.append((dw, dgamma, dbeta, dbias))
         layers = [(weights[l], None, None, None, None, None, flags[l][2]) for l in range(L)]
-        desc = _stack_desc(layers, widths, ybuf, R, outs)
+        desc = _stack_desc(layers, widths, ybuf, R, m, outs)
         du = torch.empty(B * N, widths[0], dtype=torch.float32, device=dev)   # zeroed by the library
         dv = torch.empty(B * S, widths[0], dtype=torch.float32, device=dev) if has_v else None
         dwx = torch.empty(33, widths[0], 3, dtype=torch.float32, device=dev) if has_wx else None  # [0] = result
@@ -504,18 +521,29 @@ class _GatheredStack(torch.autograd.Function):
             0 if dwx is None else xyz.data_ptr(), 0 if dwx is None else ctr.data_ptr(),
             0 if dwx is None else dwx.data_ptr(), 3, 0)
         dzbuf = torch.empty(2 * R * max([8] + widths[:-1]), dtype=torch.bfloat16, device=dev) if L > 1 else None
-        parts = torch.empty(max(_MAX_PARTS, 1024) * 2 * max(widths), dtype=torch.float32, device=dev)
+        parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
         apply_concurrency_hint()
         with on_device(dev):
-            _launch("pcb_mlp_stack_backward", 0, L, desc, 0, g.data_ptr(), 0 if arg is None else arg.data_ptr(), R, 0,
-                    0, act, pool, 0, gather, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), ws.data_ptr(),
-                    0 if dzbuf is None else dzbuf.data_ptr(), 0)
+            _launch("pcb_mlp_stack_backward", 0, m.code, L, desc, 0, g.data_ptr(), 0 if arg is None else arg.data_ptr(),
+                    R, 0, 0, act, pool, 0, gather, wbuf.data_ptr(), stz.data_ptr(), parts.data_ptr(), _MAX_PARTS, None,
+                    ws.data_ptr(), 0 if dzbuf is None else dzbuf.data_ptr(), 0)
         return (du, dv, None if dwx is None else dwx[0], None, None, None, None, None, None, None, *grads)
 
 
+def _layer_args(conv, bn, with_weight=True):
+    """(weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, counter) of one layer."""
+    momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
+    training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    track = bn.track_running_stats and bn.running_mean is not None
+    return [conv.weight if with_weight else None, conv.bias, bn.weight, bn.bias,
+            bn.running_mean if (track or not training) else None,
+            bn.running_var if (track or not training) else None,
+            training, momentum, bn.eps, _counter(bn)]
+
+
 def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0, wx=None, xyz=None, ctr=None):
-    """bf16 fused engine: the stack convs/bns applied to grouped rows whose first-layer products are
+    """bf16 engine: the stack convs/bns applied to grouped rows whose first-layer products are
     given per point: u [B*N, C0] fp32 (source points), v [B*S, C0] fp32 (centroids) or None,
     idx [B,S,ns] int64; row (s,j) of layer 0's output is u[idx[s,j]] + v[s] (+ wx (xyz_j - ctr_s)
     with wx [C0,3] fp32, xyz [B,N,3], ctr [B,S,3]).  convs[0] contributes only its bias (its weight
@@ -525,13 +553,7 @@ def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0, wx=None, xyz=None,
         raise ValueError("a gathered stack pools over its own neighbour axis")
     flat = []
     for i, (conv, bn) in enumerate(zip(convs, bns)):
-        momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
-        training = bn.training or (bn.running_mean is None and bn.running_var is None)
-        track = bn.track_running_stats and bn.running_mean is not None
-        flat += [conv.weight if i else None, conv.bias, bn.weight, bn.bias,
-                 bn.running_mean if (track or not training) else None,
-                 bn.running_var if (track or not training) else None,
-                 training, momentum, bn.eps, _counter(bn)]
+        flat += _layer_args(conv, bn, with_weight=bool(i))
     return _GatheredStack.apply(u.contiguous(), None if v is None else v.contiguous(),
                                 None if wx is None else wx.contiguous(),
                                 None if wx is None else xyz.contiguous(), None if wx is None else ctr.contiguous(),
@@ -548,28 +570,27 @@ def set_gathered(flag):
 
 
 def gathered_ok(convs, bns):
-    """The gathered first layer needs the fused bf16 engine and 8-aligned layer widths."""
-    return _GATHERED and is_bf16() and _ENGINE == "fused" and _stack_fusable(convs, bns)
+    """The gathered first layer needs bf16 rows, 8-aligned layer widths and plain BatchNorm layers."""
+    return (_GATHERED and is_bf16() and _stack_fusable(convs, bns)
+            and not any(isinstance(b, nn.SyncBatchNorm) for b in bns))
 
 
-_MAX_PARTS = 768  # upper bound of pcb_gemm_nt_partials (persistent workgroups of a gemm_nt launch)
-
-
-def _stack_desc(layers, widths, ybuf, R, outs=None):
+def _stack_desc(layers, widths, ybuf, R, m, outs=None):
     """Host descriptor table of pcb_mlp_stack_forward/backward: 16 int64 per layer (pcb_hip.h)."""
     vals, yoff = [], 0
     ybase = ybuf.data_ptr()
+    esize = ybuf.element_size()
     for l, t in enumerate(layers):
         w, bias, gamma, beta, rm, rv, training = t[:7]
         if w is not None and not (w.is_contiguous() and w.dtype == torch.float32):
-            raise TypeError("fused bf16 layers expect contiguous fp32 master weights")
+            raise TypeError("fused layers expect contiguous fp32 master weights")
         C = widths[l]
         o = outs[l] if outs is not None else (None, None, None, None)
         vals += [0 if w is None else w.data_ptr(),
                  0 if bias is None else bias.data_ptr(), 0 if gamma is None else gamma.data_ptr(),
                  0 if beta is None else beta.data_ptr(), 0 if rm is None else rm.data_ptr(),
                  0 if rv is None else rv.data_ptr(), C, 0 if w is None else w.numel() // C, int(bool(training)),
-                 ybase + 2 * yoff,
+                 ybase + esize * yoff,
                  0 if o[0] is None else o[0].data_ptr(), 0 if o[1] is None else o[1].data_ptr(),
                  0 if o[2] is None else o[2].data_ptr(), 0 if o[3] is None else o[3].data_ptr(),
                  t[9].data_ptr() if (len(t) > 9 and t[9] is not None) else 0, 0]
@@ -578,24 +599,21 @@ def _stack_desc(layers, widths, ybuf, R, outs=None):
 
 
 def _stack_fusable(convs, bns):
-    return all(c.out_channels % 8 == 0 and not isinstance(b, nn.SyncBatchNorm) for c, b in zip(convs, bns))
+    q = mode().q
+    return all(c.out_channels % q == 0 and c.out_channels <= 256 * q for c in convs)
 
 
 def _fused_stack(convs, bns, x, act, pool, perm, stat_repeat=1):
-    kp = x.shape[1] if perm != 0 else pad8(convs[0].in_channels)
-    xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
+    m = mode()
+    kp = x.shape[1] if perm != 0 else m.pad(convs[0].in_channels)
+    xr = x if (x.dtype == m.dtype and x.shape[1] == kp and x.is_contiguous()) else _rows(x, kp, m)
+    use_sync, group = _sync_group(bns)
     flat = []
     # num_batches_tracked += 1 (nn.BatchNorm.forward does it per module) rides along in the layer's
     # finalize kernel; the count itself is only read on the host when momentum=None
     for conv, bn in zip(convs, bns):
-        momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
-        training = bn.training or (bn.running_mean is None and bn.running_var is None)
-        track = bn.track_running_stats and bn.running_mean is not None
-        flat += [conv.weight, conv.bias, bn.weight, bn.bias,
-                 bn.running_mean if (track or not training) else None,
-                 bn.running_var if (track or not training) else None,
-                 training, momentum, bn.eps, _counter(bn)]
-    return _FusedStack.apply(xr, act, pool, perm, stat_repeat, len(convs), *flat)
+        flat += _layer_args(conv, bn)
+    return _FusedStack.apply(xr, act, pool, perm, stat_repeat, len(convs), m, group if use_sync else False, *flat)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -604,100 +622,82 @@ def _fused_stack(convs, bns, x, act, pool, perm, stat_repeat=1):
 def conv_bn_act(conv, bn, x, act=ACT_RELU, pool=0, perm=0, stat_repeat=1):
     """act(bn(conv(x))) on rows x [R, K]; with pool = ns also the max over each ns consecutive rows.
 
-    perm = C > 0: x was written by pcb_group_rows_bf16 (C feature columns first, then the 3 centred
-    coordinates); bf16 mode only.  stat_repeat = r > 1 (bf16 fused engine only): every row stands
-    for r identical samples, which only matters for the unbiased running-variance factor.
+    perm = C > 0: x was written by group_rows (C feature columns first, then the 3 centred
+    coordinates); perm = -D < 0: by interpolate_concat.  stat_repeat = r > 1: every row stands for r
+    identical samples, which only matters for the unbiased running-variance factor.
     Returns [R, Cout] or [R/pool, Cout] in the mode's dtype."""
-    if not is_bf16():
-        y = _act_torch(_bn_rows_fp32(bn, F.linear(x, _weight2d(conv), conv.bias)), act)
-        if pool:
-            y = y.view(-1, pool, y.shape[1]).max(dim=1)[0]
-        return y
-    if isinstance(bn, nn.SyncBatchNorm):
-        raise NotImplementedError("SyncBatchNorm is supported in fp32 mode only")
-    if conv.out_channels % 8 != 0:
-        # narrow odd widths (not used by the reference's networks): unfused torch ops in bf16
-        y = F.linear(x.to(torch.bfloat16), _weight2d(conv).to(torch.bfloat16),
-                     None if conv.bias is None else conv.bias.to(torch.bfloat16))
-        y = _act_torch(_bn_rows_fp32(bn, y.float()), act).to(torch.bfloat16)
-        if pool:
-            y = y.view(-1, pool, y.shape[1]).max(dim=1)[0]
-        return y
-    if _ENGINE == "fused":
+    if _stack_fusable([conv], [bn]):
         return _fused_stack([conv], [bn], x, act, pool, perm, stat_repeat)
-    if stat_repeat != 1:
-        raise NotImplementedError("stat_repeat needs the fused engine")
-    kp = x.shape[1] if perm != 0 else pad8(conv.in_channels)
-    xr = x if (x.dtype == torch.bfloat16 and x.shape[1] == kp and x.is_contiguous()) else _rows_bf16(x, kp)
-    momentum = _bn_bookkeeping(bn)
-    training = bn.training or (bn.running_mean is None and bn.running_var is None)
-    track = bn.track_running_stats and bn.running_mean is not None
-    return _LinearBNAct.apply(
-        xr, conv.weight, conv.bias, bn.weight, bn.bias,
-        bn.running_mean if (track or not training) else None,
-        bn.running_var if (track or not training) else None,
-        training, momentum, bn.eps, act, pool, perm)
+    # widths that are not multiples of a 16-byte chunk (not used by the reference's networks): ATen ops
+    if perm != 0 or stat_repeat != 1:
+        raise NotImplementedError("column layouts / repeated rows need a channel count the engine takes")
+    m = mode()
+    y = F.linear(x.to(m.dtype), _weight2d(conv).to(m.dtype), None if conv.bias is None else conv.bias.to(m.dtype))
+    y = _act_torch(_bn_rows_fp32(bn, y.float()), act).to(m.dtype)
+    if pool:
+        y = y.view(-1, pool, y.shape[1]).max(dim=1)[0]
+    return y
 
 
 _gap_rows = {}
 
 
-def _gap_row_index(n, d, device):
+def _gap_row_index(n, d, q, device):
     """Row numbers of the n real outputs inside the interpolate+concat column layout (cached)."""
-    key = (n, d, device)
+    key = (n, d, q, device)
     if key not in _gap_rows:
-        dp = pad8(d)
+        dp = (d + q - 1) // q * q
         _gap_rows[key] = torch.cat([torch.arange(d, device=device), dp + torch.arange(n - d, device=device)])
     return _gap_rows[key]
 
 
 class _LinearBias(torch.autograd.Function):
-    """y = x W^T + b on bf16 rows (no BatchNorm): operands prepared by one kernel, the product with
+    """y = x W^T + b on rows (no BatchNorm): operands prepared by one kernel, the product with
     the bias added in the GEMM epilogue.  Backward: input gradient with the same GEMM on W^T, weight
     gradient with the split-row MFMA kernel (fp32, no atomics), bias gradient as a column sum."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_gap):
+    def forward(ctx, x, weight, bias, out_gap, m):
         """out_gap = D > 0: the output keeps the interpolate_concat column layout (first D outputs
-        in place, the rest from column pad8(D); untouched columns are exactly zero) and is returned
+        in place, the rest from column pad(D); untouched columns are exactly zero) and is returned
         with all its padded columns; out_gap = 0: plain [R, n] output."""
         w = weight.reshape(weight.shape[0], -1)
         if not (w.is_contiguous() and w.dtype == torch.float32):
-            raise TypeError("bf16 layers expect contiguous fp32 master weights")
+            raise TypeError("fused layers expect contiguous fp32 master weights")
         n, k = w.shape
         R, kp = x.shape
         dev = x.device
-        npad = pad8(pad8(out_gap) + n - out_gap) if out_gap else pad8(n)
+        npad = m.pad(m.pad(out_gap) + n - out_gap) if out_gap else m.pad(n)
         need_dx = ctx.needs_input_grad[0]
         cache_key = hit = None
         if not torch.is_grad_enabled():  # constant weights: keep the prepared operands (see _eval_lookup)
-            cache_key, versions, hit = _eval_lookup([(weight, bias)], weight, ("linear", kp, int(out_gap)))
+            cache_key, versions, hit = _eval_lookup([(weight, bias)], weight, ("linear", kp, int(out_gap), m.code))
         if hit is not None:
             wp, wt, bp = hit
         else:
-            wp = torch.empty(npad, kp, dtype=torch.bfloat16, device=dev)
-            wt = torch.empty(kp, npad, dtype=torch.bfloat16, device=dev) if need_dx else None
+            wp = torch.empty(npad, kp, dtype=m.dtype, device=dev)
+            wt = torch.empty(kp, npad, dtype=m.dtype, device=dev) if need_dx else None
             bp = torch.empty(npad, dtype=torch.float32, device=dev)
-        y = torch.empty(R, npad, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(R, npad, dtype=m.dtype, device=dev)
         with on_device(dev):
             if hit is None:
-                _launch("pcb_prep_linear_bias_bf16", npad * kp, w.data_ptr(), 0 if bias is None else bias.data_ptr(), n, k,
+                _launch("pcb_prep_linear_bias_" + m.sfx, npad * kp, w.data_ptr(), 0 if bias is None else bias.data_ptr(), n, k,
                         npad, kp, int(out_gap), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), bp.data_ptr())
-            _launch("pcb_gemm_nt_bias_bf16", 2 * R * (npad + kp), x.data_ptr(), wp.data_ptr(), bp.data_ptr(), R, npad, kp,
+            _launch("pcb_gemm_nt_bias_" + m.sfx, 2 * R * (npad + kp), x.data_ptr(), wp.data_ptr(), bp.data_ptr(), R, npad, kp,
                     y.data_ptr())
         if cache_key is not None and hit is None:
             _eval_store(cache_key, weight, versions, (wp, wt, bp))
         ctx.save_for_backward(x, wt)
-        ctx.cfg = (weight.shape, n, k, bias is not None, int(out_gap), npad)
+        ctx.cfg = (weight.shape, n, k, bias is not None, int(out_gap), npad, m)
         return y if out_gap else y[:, :n]
 
     @staticmethod
     def backward(ctx, g):
         x, wt = ctx.saved_tensors
-        wshape, n, k, has_bias, out_gap, npad = ctx.cfg
+        wshape, n, k, has_bias, out_gap, npad, m = ctx.cfg
         R, kp = x.shape
         dev = x.device
-        gy = g.to(torch.bfloat16)
+        gy = g.to(m.dtype)
         gy = gy.contiguous() if gy.shape[1] == npad else F.pad(gy, (0, npad - gy.shape[1]))
         dx = None
         dw = torch.empty(npad, k, dtype=torch.float32, device=dev)
@@ -706,27 +706,25 @@ class _LinearBias(torch.autograd.Function):
         sums = torch.zeros(2, npad, dtype=torch.float32, device=dev)
         with on_device(dev):
             if wt is not None:
-                dx = torch.empty(R, kp, dtype=torch.bfloat16, device=dev)
-                _launch("pcb_gemm_nt_bf16", 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 0, 0, wt.data_ptr(),
-                        R, kp, npad, dx.data_ptr(), 0)
+                dx = torch.empty(R, kp, dtype=m.dtype, device=dev)
+                _launch("pcb_gemm_nt_" + m.sfx, 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 0, 0, wt.data_ptr(),
+                        R, kp, npad, dx.data_ptr(), 0, 0)
             # dW straight in the real [npad, k] layout (the padding columns of x dropped)
-            _launch("pcb_gemm_tn_bf16", 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
+            _launch("pcb_gemm_tn_" + m.sfx, 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
                     0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr(), k, 0)
             if has_bias:
-                _launch("pcb_colstats_bf16", R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
+                _launch("pcb_colstats_" + m.sfx, R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
         if not out_gap:
-            return dx, dw[:n].reshape(wshape), (sums[0, :n].clone() if has_bias else None), None
-        rows = _gap_row_index(n, out_gap, dev)
-        return dx, dw[rows].reshape(wshape), (sums[0, rows] if has_bias else None), None
+            return dx, dw[:n].reshape(wshape), (sums[0, :n].clone() if has_bias else None), None, None
+        rows = _gap_row_index(n, out_gap, m.q, dev)
+        return dx, dw[rows].reshape(wshape), (sums[0, rows] if has_bias else None), None, None
 
 
 def conv_rows(conv, x, out_dtype=None, out_gap=0):
-    """Plain 1x1 conv (with bias) on rows, no BatchNorm.  bf16 mode computes in bf16; out_gap: see
-    _LinearBias.forward (bf16 mode only)."""
-    if not is_bf16():
-        return F.linear(x, _weight2d(conv), conv.bias)
-    xr = _rows_bf16(x, pad8(x.shape[1]))
-    y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap)
+    """Plain 1x1 conv (with bias) on rows, no BatchNorm; out_gap: see _LinearBias.forward."""
+    m = mode()
+    xr = _rows(x, m.pad(x.shape[1]), m)
+    y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m)
     return y if out_dtype is None else y.to(out_dtype)
 
 
@@ -747,151 +745,156 @@ def build_interp_csr(idx, S):
     return offsets, entries
 
 
-class _InterpConcatBF16(torch.autograd.Function):
+class _InterpConcat(torch.autograd.Function):
     """[skip | interpolated] rows of FeaturePropagation (models/pointnet2_utils.py:191-203) written
-    once, as the bf16 input buffer of the following GEMM: columns [0:D1) = skip features,
-    [pad8(D1) : pad8(D1)+C) = inverse-distance interpolation of feat over the k nearest (from
+    once, as the input buffer of the following GEMM: columns [0:D1) = skip features,
+    [pad(D1) : pad(D1)+C) = inverse-distance interpolation of feat over the k nearest (from
     three_nn), everything else zero.  Backward: the interpolation's gradient is reduced per target
     row over an inverted index (no atomics)."""
 
     @staticmethod
-    def forward(ctx, skip, feat, d2, idx, offsets, entries):
+    def forward(ctx, skip, feat, d2, idx, offsets, entries, m):
         B, S, C = feat.shape
         N, k = d2.shape[1], d2.shape[2]
         D1 = 0 if skip is None else skip.shape[1]
-        dp = pad8(D1)
+        dp = m.pad(D1)
         dev = feat.device
-        out = torch.empty(B * N, dp + C, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(B * N, dp + C, dtype=m.dtype, device=dev)
         if skip is not None:
             out[:, :D1] = skip
             if dp > D1:
                 out[:, D1:dp] = 0
         w = torch.empty(B, N, k, dtype=torch.float32, device=dev)
         with on_device(dev):
-            _launch("pcb_interpolate_bf16", 2 * B * N * C, feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S, C,
-                    k, out.data_ptr(), dp + C, dp, w.data_ptr())
+            _launch("pcb_interpolate_bf16" if m.code == 0 else "pcb_interpolate_rows_f32", 2 * B * N * C, feat.data_ptr(),
+                    d2.data_ptr(), idx.data_ptr(), B, N, S, C, k, out.data_ptr(), dp + C, dp, w.data_ptr())
         ctx.save_for_backward(idx, w, offsets, entries)
-        ctx.shape = (B, N, S, C, k, D1, dp)
+        ctx.shape = (B, N, S, C, k, D1, dp, m)
         return out
 
     @staticmethod
     def backward(ctx, g):
         idx, w, offsets, entries = ctx.saved_tensors
-        B, N, S, C, k, D1, dp = ctx.shape
+        B, N, S, C, k, D1, dp, m = ctx.shape
         dev = g.device
-        g = g.contiguous()
+        g = g.to(m.dtype).contiguous()
         if offsets is None:  # not built ahead by a prefetch
             offsets, entries = build_interp_csr(idx, S)
-        gfeat = torch.empty(B, S, C, dtype=torch.bfloat16, device=dev)
+        gfeat = torch.empty(B, S, C, dtype=m.dtype, device=dev)
         with on_device(dev):
-            _launch("pcb_interpolate_bwd_csr_bf16", 2 * B * N * C * k, g.data_ptr(), dp + C, dp, w.data_ptr(),
+            _launch("pcb_interpolate_bwd_csr_" + m.sfx, 2 * B * N * C * k, g.data_ptr(), dp + C, dp, w.data_ptr(),
                     offsets.data_ptr(), entries.data_ptr(), B, N, S, C, k, gfeat.data_ptr())
         gskip = g[:, :D1] if (D1 and ctx.needs_input_grad[0]) else None
-        return gskip, gfeat, None, None, None, None
+        return gskip, gfeat, None, None, None, None, None
 
 
 def interpolate_concat(skip_rows, feat_bsc, d2, idx, csr=None):
-    """bf16 mode: (rows [B*N, pad8(D1)+C] bf16, perm) with perm = -D1 describing the column layout
-    for conv_bn_act / mlp_rows / conv_rows (0 when there is no gap).  Needs C % 8 == 0.
+    """(rows [B*N, pad(D1)+C], perm) with perm = -D1 describing the column layout for conv_bn_act /
+    mlp_rows / conv_rows (0 when there is no gap).  Needs C to be a multiple of the 16-byte chunk.
     csr = build_interp_csr(idx, S) if the caller already has it (the backward pass builds it otherwise)."""
-    feat = feat_bsc.to(torch.bfloat16).contiguous()
-    skip = None if skip_rows is None else skip_rows.to(torch.bfloat16)
+    m = mode()
+    feat = feat_bsc.to(m.dtype).contiguous()
+    skip = None if skip_rows is None else skip_rows.to(m.dtype)
     offsets, entries = csr if csr is not None else (None, None)
-    rows = _InterpConcatBF16.apply(skip, feat, d2.contiguous(), idx.contiguous(), offsets, entries)
+    rows = _InterpConcat.apply(skip, feat, d2.contiguous(), idx.contiguous(), offsets, entries, m)
     d1 = 0 if skip is None else skip.shape[1]
-    return rows, (-d1 if d1 % 8 else 0)
+    return rows, (-d1 if d1 % m.q else 0)
 
 
 class _BNActRows(torch.autograd.Function):
-    """act(BatchNorm(y)) on bf16 rows [R,C] with no GEMM in front (DGCNN.local_bn): one statistics
+    """act(BatchNorm(y)) on rows [R,C] with no GEMM in front (DGCNN.local_bn): one statistics
     pass, the finalize kernel, one apply pass; backward = one reduce + one apply pass (csrc/rowbn.hip)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, act):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, act, m, nbt):
         R, C = y.shape
         dev = y.device
         stats = torch.zeros(6, C, dtype=torch.float32, device=dev)  # sums(2) | scale | shift | mean | invstd
-        out = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(R, C, dtype=m.dtype, device=dev)
+        if training:
+            note_parameter_update()
         with on_device(dev):
             if training:
-                _launch("pcb_colstats_bf16", R * C, y.data_ptr(), R, C, stats[0:2].data_ptr())
+                _launch("pcb_colstats_" + m.sfx, R * C, y.data_ptr(), R, C, stats[0:2].data_ptr())
             _launch("pcb_bn_finalize", C, stats[0:2].data_ptr(), 1, R, 0, C,
                     0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(), 0,
                     0 if running_mean is None else running_mean.data_ptr(),
                     0 if running_var is None else running_var.data_ptr(),
                     float(momentum), float(eps), int(training), stats[2].data_ptr(), stats[3].data_ptr(),
-                    stats[4].data_ptr(), stats[5].data_ptr(), 0)
-            _launch("pcb_bn_act_bf16", R * C, y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), R, C, act,
+                    stats[4].data_ptr(), stats[5].data_ptr(), 0 if nbt is None else nbt.data_ptr())
+            _launch("pcb_bn_act_" + m.sfx, R * C, y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), R, C, act,
                     out.data_ptr())
         ctx.save_for_backward(y, stats)
-        ctx.cfg = (int(training), act, gamma is not None)
+        ctx.cfg = (int(training), act, gamma is not None, m)
         return out
 
     @staticmethod
     def backward(ctx, g):
         y, stats = ctx.saved_tensors
-        training, act, has_affine = ctx.cfg
+        training, act, has_affine, m = ctx.cfg
         R, C = y.shape
         dev = y.device
         bsums = torch.zeros(2, C, dtype=torch.float32, device=dev)
-        dy = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-        gb = g.to(torch.bfloat16).contiguous()
+        dy = torch.empty(R, C, dtype=m.dtype, device=dev)
+        gb = g.to(m.dtype).contiguous()
         with on_device(dev):
-            _launch("pcb_bn_act_bwd_bf16", R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+            _launch("pcb_bn_act_bwd_" + m.sfx, R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
                     stats[4].data_ptr(), stats[5].data_ptr(), R, C, act, training, bsums.data_ptr(), dy.data_ptr())
         return (dy, bsums[1].clone() if has_affine else None, bsums[0].clone() if has_affine else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 class _Gate(torch.autograd.Function):
-    """x * sigmoid(a) on bf16 rows in one pass each way (pcb_gate_bf16 / pcb_gate_bwd_bf16)."""
+    """x * sigmoid(a) on rows in one pass each way (pcb_gate_* / pcb_gate_bwd_*)."""
 
     @staticmethod
-    def forward(ctx, x, a):
+    def forward(ctx, x, a, m):
         out = torch.empty_like(x)
         with on_device(x.device):
-            _launch("pcb_gate_bf16", x.numel(), x.data_ptr(), a.data_ptr(), out.data_ptr(), x.numel())
+            _launch("pcb_gate_" + m.sfx, x.numel(), x.data_ptr(), a.data_ptr(), out.data_ptr(), x.numel())
         ctx.save_for_backward(x, a)
+        ctx.m = m
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, a = ctx.saved_tensors
-        g = g.to(torch.bfloat16).contiguous()
+        m = ctx.m
+        g = g.to(m.dtype).contiguous()
         dx, da = torch.empty_like(x), torch.empty_like(a)
         with on_device(x.device):
-            _launch("pcb_gate_bwd_bf16", 3 * x.numel(), g.data_ptr(), x.data_ptr(), a.data_ptr(), dx.data_ptr(),
+            _launch("pcb_gate_bwd_" + m.sfx, 3 * x.numel(), g.data_ptr(), x.data_ptr(), a.data_ptr(), dx.data_ptr(),
                     da.data_ptr(), x.numel())
-        return dx, da
+        return dx, da, None
 
 
 def gate_rows(x, a):
     """x * sigmoid(a) (the channel-attention gate, reference pointnet2_utils.py:279-280)."""
-    if (is_bf16() and x.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and x.shape == a.shape
-            and x.is_contiguous() and a.is_contiguous() and x.numel() % 8 == 0):
-        return _Gate.apply(x, a)
+    m = mode()
+    if (x.dtype == m.dtype and a.dtype == m.dtype and x.shape == a.shape
+            and x.is_contiguous() and a.is_contiguous() and x.numel() % m.q == 0):
+        return _Gate.apply(x, a, m)
     return x * torch.sigmoid(a)
 
 
 def bn_act_rows(bn, x, act=ACT_NONE):
     """BatchNorm (+ activation) on rows without a preceding conv (DGCNN.local_bn)."""
-    if not is_bf16():
-        return _act_torch(_bn_rows_fp32(bn, x), act)
-    if isinstance(bn, nn.SyncBatchNorm) or x.shape[1] % 8 != 0 or _ENGINE != "fused":
-        return _act_torch(_bn_rows_fp32(bn, x.float()), act).to(torch.bfloat16)
-    momentum = _bn_bookkeeping(bn)
+    m = mode()
+    if isinstance(bn, nn.SyncBatchNorm) or x.shape[1] % m.q != 0 or x.shape[1] > 256 * m.q:
+        return _act_torch(_bn_rows_fp32(bn, x.float()), act).to(m.dtype)
+    momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     track = bn.track_running_stats and bn.running_mean is not None
-    return _BNActRows.apply(x.to(torch.bfloat16).contiguous(), bn.weight, bn.bias,
+    return _BNActRows.apply(x.to(m.dtype).contiguous(), bn.weight, bn.bias,
                             bn.running_mean if (track or not training) else None,
                             bn.running_var if (track or not training) else None,
-                            training, momentum, bn.eps, act)
+                            training, momentum, bn.eps, act, m, _counter(bn))
 
 
 def mlp_rows(convs, bns, x, act=ACT_RELU, pool=0, perm=0):
     """A stack of conv_bn_act layers; the last one pools if pool > 0."""
     n = len(convs)
-    if is_bf16() and _ENGINE == "fused" and _stack_fusable(convs, bns):
+    if _stack_fusable(convs, bns):
         return _fused_stack(list(convs), list(bns), x, act, pool, perm)
     for i, (conv, bn) in enumerate(zip(convs, bns)):
         x = conv_bn_act(conv, bn, x, act, pool if i == n - 1 else 0, perm if i == 0 else 0)
@@ -899,45 +902,40 @@ def mlp_rows(convs, bns, x, act=ACT_RELU, pool=0, perm=0):
 
 
 def group_rows(xyz, new_xyz, feat, idx):
-    """Grouped GEMM input rows for a set-abstraction level.
-
-    fp32 mode: ops.group_points -> [B*S*ns, 3+C] fp32, coordinates first (reference order), perm 0.
-    bf16 mode: pcb_group_rows_bf16 -> [B*S*ns, Kp] bf16, features first, perm = C (see conv_bn_act).
-    Returns (rows, perm)."""
-    from . import ops
-    B, S, ns = idx.shape
-    if not is_bf16():
-        g = ops.group_points(xyz, new_xyz, feat, idx)
-        return g.view(B * S * ns, g.shape[-1]), 0
-    return _GroupRowsBF16.apply(xyz, new_xyz, feat, idx), (0 if feat is None else feat.shape[2])
+    """Grouped GEMM input rows for a set-abstraction level: pcb_group_rows_* -> [B*S*ns, Kp] in the
+    mode's row type, FEATURES FIRST, then the 3 centred coordinates, zero padded to a 16-byte chunk
+    (the reference's order is coordinates first, :56 / :347; the weight columns are permuted to match
+    when the stack's operands are prepared).  Returns (rows, perm) with perm = C (see conv_bn_act)."""
+    m = mode()
+    return _GroupRows.apply(xyz, new_xyz, feat, idx, m), (0 if feat is None else feat.shape[2])
 
 
-class _GroupRowsBF16(torch.autograd.Function):
+class _GroupRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, new_xyz, feat, idx):
+    def forward(ctx, xyz, new_xyz, feat, idx, m):
         B, N, _ = xyz.shape
         S, ns = idx.shape[1], idx.shape[2]
         C = 0 if feat is None else feat.shape[2]
-        kp = pad8(C + 3)
+        kp = m.pad(C + 3)
         if feat is not None:
-            feat = feat.to(torch.bfloat16).contiguous()
-        out = torch.empty(B * S * ns, kp, dtype=torch.bfloat16, device=xyz.device)
+            feat = feat.to(m.dtype).contiguous()
+        out = torch.empty(B * S * ns, kp, dtype=m.dtype, device=xyz.device)
         with on_device(xyz.device):
-            _launch("pcb_group_rows_bf16", B * S * ns * kp, xyz.data_ptr(), new_xyz.data_ptr(),
+            _launch("pcb_group_rows_" + m.sfx, B * S * ns * kp, xyz.data_ptr(), new_xyz.data_ptr(),
                     0 if feat is None else feat.data_ptr(), idx.data_ptr(), B, N, S, ns, C, kp, out.data_ptr())
         ctx.save_for_backward(idx)
-        ctx.shape = (B, N, S, ns, C, kp)
+        ctx.shape = (B, N, S, ns, C, kp, m)
         return out
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        B, N, S, ns, C, kp = ctx.shape
+        B, N, S, ns, C, kp, m = ctx.shape
         if C == 0 or not ctx.needs_input_grad[2]:
-            return None, None, None, None
-        g = g.contiguous()
+            return None, None, None, None, None
+        g = g.to(m.dtype).contiguous()
         gf = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
         with on_device(g.device):
-            _launch("pcb_group_rows_bf16_bwd", B * S * ns * C, g.data_ptr(), idx.data_ptr(), B, N, S, ns, C, kp,
+            _launch("pcb_group_rows_%s_bwd" % m.sfx, B * S * ns * C, g.data_ptr(), idx.data_ptr(), B, N, S, ns, C, kp,
                     gf.data_ptr())
-        return None, None, gf, None
+        return None, None, gf, None, None

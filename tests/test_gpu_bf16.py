@@ -57,11 +57,10 @@ def _close(a, b, tol):
     return ok
 
 
-@pytest.mark.parametrize("engine", ["fused", "staged"])
 @pytest.mark.parametrize("R,K,C,act,pool", [(4096, 8, 64, 1, 0), (2048, 264, 128, 1, 16), (1536, 128, 64, 2, 8),
                                             (999 * 4, 72, 256, 0, 0), (640, 520, 512, 1, 32), (77 * 3, 16, 24, 1, 3),
                                             (1024, 264, 256, 1, 8), (1000, 264, 256, 2, 0)])
-def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, engine, R, K, C, act, pool):
+def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, R, K, C, act, pool):
     torch.manual_seed(R + C)
     dev = "cuda"
     x = torch.randn(R, K, device=dev).to(torch.bfloat16).requires_grad_(True)
@@ -74,9 +73,7 @@ def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, engine, R, K, C, act, 
     bn_ref.load_state_dict(bn.state_dict())
 
     rm.set_precision("bf16")
-    rm.set_engine(engine)
     out = rm.conv_bn_act(conv, bn, x, act, pool)
-    rm.set_engine("fused")
     rm.set_precision("fp32")
     assert out.dtype == torch.bfloat16 and out.shape == (R // pool if pool else R, C)
 
@@ -295,6 +292,16 @@ def test_interpolate_concat_bf16_forward_backward(rm, D1, C, k):
         assert torch.equal(skip.grad, gr[:, :D1])
 
 
+def _unpad_weight_grad(dwp, k, perm, q=8):
+    """Inverse of rowmlp.padded_weight_from's column layout for a weight gradient [Cout, kp] -> [Cout, k]."""
+    if perm > 0:
+        return torch.cat([dwp[:, perm:perm + 3], dwp[:, :perm]], dim=1)
+    if perm < 0:
+        d, dp = -perm, (-perm + q - 1) // q * q
+        return torch.cat([dwp[:, :d], dwp[:, dp:dp + k - d]], dim=1)
+    return dwp[:, :k]
+
+
 @pytest.mark.parametrize("perm,k,kp", [(0, 6, 8), (0, 64, 64), (3, 6, 8), (128, 131, 136), (-3, 259, 264), (-5, 13, 16)])
 def test_prep_weights_and_wgrad_layout_match_host_reference(rm, perm, k, kp):
     """pcb_prep_weights_bf16 == padded_weight_from (+ transpose); pcb_gemm_tn_bf16's out_cols/out_perm
@@ -322,7 +329,7 @@ def test_prep_weights_and_wgrad_layout_match_host_reference(rm, perm, k, kp):
     for out, cols, pm in ((full, 0, 0), (real, k, perm)):
         _launch("pcb_gemm_tn_bf16", 0, 0, dz.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(), 0, 0, 0, R, C, kp,
                 ws.data_ptr(), out.data_ptr(), cols, pm)
-    assert torch.equal(real, rm._unpad_weight_grad(full, k, perm).contiguous())
+    assert torch.equal(real, _unpad_weight_grad(full, k, perm).contiguous())
     assert _close(full, dz.float().t() @ x.float(), 2e-3)
 
 
@@ -496,7 +503,7 @@ def test_gather_add_and_scatter_dy_entry_points(rm, pooled, with_v, with_wx, C):
     y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
     slabs = torch.empty(npart, 2, C, device=dev)
     _launch("pcb_gather_add_bf16", 0, u.data_ptr(), 0 if v is None else v.data_ptr(), idx.data_ptr(), B, N, S, ns, C,
-            xyz.data_ptr(), ctr.data_ptr(), 0 if wx is None else wx.data_ptr(), 3, y.data_ptr(), slabs.data_ptr())
+            xyz.data_ptr(), ctr.data_ptr(), 0 if wx is None else wx.data_ptr(), 3, y.data_ptr(), slabs.data_ptr(), npart)
     src = (idx + torch.arange(B, device=dev).view(B, 1, 1) * N).reshape(-1)
     grp = torch.arange(B * S, device=dev).repeat_interleave(ns)
     ref = u[src]
