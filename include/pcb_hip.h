@@ -268,7 +268,7 @@ int pcb_edge_features_bwd(const float *grad_out, const int64_t *idx, int B, int 
 /* Every entry point of this section exists for both row types: *_bf16 (C % 8 == 0, C <= 2048) and
  * *_f32 (C % 4 == 0, C <= 1024) with the same arguments. */
 
-/* sums[0][c] += sum_r y[r][c]; sums[1][c] += sum_r y[r][c]^2.  sums [2,C] fp32, zeroed by the caller. */
+/* sums[0][c] += sum_r y[r][c]; sums[1][c] += sum_r y[r][c]^2.  sums [2,C] fp32, zeroed by the caller (any C that is a multiple of the chunk). */
 int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream);
 int pcb_colstats_f32(const void *y, long rows, int C, float *sums, void *stream);
 
@@ -581,7 +581,7 @@ int pcb_gate_bwd_f32(const void *g, const void *x, const void *a, void *dx, void
  * preparation and the per-layer BatchNorm finalize are skipped (inference with constant weights).
  * Backward only: g = dz [R,C_last] (pool 0) or dout fp32 [R/ns,C_last]; workspace fp32, >= the
  * SUM of pcb_gemm_tn_workspace(R,C_l,Kp_l) over the layers that have a dW (each keeps its slabs until
- * one launch at the end of the pass sums them all); dzbuf [2][R][max width] (L > 1); dx [R,Kp] or NULL.
+ * one launch at the end of the pass sums them all); dzbuf [2][R][max(8, Kp, widths of all but the last layer)] (L > 1); dx [R,Kp] or NULL.
  */
 #define PCB_STACK_MAX_LAYERS 16
 typedef struct pcb_sync {

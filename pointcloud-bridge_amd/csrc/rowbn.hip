@@ -55,23 +55,28 @@ __device__ __forceinline__ void block_moments(const float *s, const float *q, in
 // ---------------------------------------------------------------------------------------------
 // Column statistics: sums[0][c] = sum_r y[r][c], sums[1][c] = sum_r y[r][c]^2   (C % E == 0, C/E <= 256)
 // Lane t owns channel chunk t % CT and walks rows t / CT, + RT, ...
+// A launch covers C columns of rows that are `ld` vectors apart (C == the row width, or a column block
+// of a wider matrix: blockIdx.y picks the block; the moments of column c go to sums[c], sums[Call + c]).
 template <typename T>
-__global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restrict__ y, long rows, int C,
-                                                             float *__restrict__ sums, int slabs)
+__global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restrict__ y, long rows, int C, int Call,
+                                                             float *__restrict__ sums)
 {
     constexpr int E = RowVec<T>::E;
     __shared__ float red[kThreads * 2 * E];
-    const int CT = C / E;
+    const int c0 = blockIdx.y * C;             // first column of this block
+    const int Cb = Call - c0 < C ? Call - c0 : C;  // columns in this block
+    const int CT = Cb / E;
     const int RT = kThreads / CT;          // row-lanes per block (CT <= 256)
     const int cc = threadIdx.x % CT;
     const int rl = threadIdx.x / CT;
+    const long ld = Call / E;
     float s[E], q[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) s[i] = q[i] = 0.0f;
     if (rl < RT) {
         for (long r = (long)blockIdx.x * RT + rl; r < rows; r += (long)gridDim.x * RT) {
             float f[E];
-            RowVec<T>::unpack(y[r * CT + cc], f);
+            RowVec<T>::unpack(y[r * ld + c0 / E + cc], f);
 #pragma unroll
             for (int i = 0; i < E; ++i) {
                 s[i] += f[i];
@@ -79,7 +84,18 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restr
             }
         }
     }
-    block_moments<E>(s, q, C, red, sums, slabs);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        red[threadIdx.x * 2 * E + i] = s[i];
+        red[threadIdx.x * 2 * E + E + i] = q[i];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * Cb; o += kThreads) {
+        const int m = o / Cb, c = o % Cb;
+        float a = 0.0f;
+        for (int r = 0; r < RT; ++r) a += red[(r * CT + c / E) * 2 * E + m * E + (c % E)];
+        atomicAdd(&sums[(long)m * Call + c0 + c], a);
+    }
 }
 
 // out[i] = sum_k slabs[k][i], i < n, in slab order (SyncBatchNorm: the local totals that travel
@@ -478,11 +494,15 @@ inline bool bad_c(int C)
 template <typename T>
 int colstats(const void *y, long rows, int C, float *sums, void *stream)
 {
+    constexpr int E = RowVec<T>::E;
     if (!y || !sums || rows <= 0) return PCB_ERR_INVALID_ARG;
-    if (bad_c<T>(C)) return PCB_ERR_UNSUPPORTED;
-    const int RT = kThreads / (C / RowVec<T>::E);
-    hipLaunchKernelGGL(colstats_kernel<T>, dim3(grid_for(rows, RT * 8, 2048)), dim3(kThreads), 0,
-                       (hipStream_t)stream, (const uint4 *)y, rows, C, sums, 0);
+    if (C <= 0 || (C % E) != 0) return PCB_ERR_UNSUPPORTED;
+    // column blocks of at most 256 vectors (one lane per vector and row-lane)
+    const int Cblk = C < 256 * E ? C : 256 * E;
+    const int nblk = (C + Cblk - 1) / Cblk;
+    const int RT = kThreads / (Cblk / E);
+    hipLaunchKernelGGL(colstats_kernel<T>, dim3(grid_for(rows, RT * 8, 2048), nblk), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const uint4 *)y, rows, Cblk, C, sums);
     return pcb_check_launch();
 }
 

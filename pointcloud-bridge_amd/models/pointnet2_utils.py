@@ -509,6 +509,6 @@ class EnhancedFeaturePropagation(nn.Module):
         identity = x
         x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x, perm=perm)
         if self.skip_connection:
-            x = x + identity                                        # :292-293
+            x = x + rowmlp.ungap_rows(identity, perm)               # :292-293
         x = x + edge                                                # :296
         return x.view(B, N, -1).transpose(1, 2)

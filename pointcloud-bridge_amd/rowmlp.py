@@ -354,7 +354,7 @@ class _FusedStack(torch.autograd.Function):
         desc = _stack_desc(layers, widths, ybuf, R, m, outs)
         want_dx = bool(ctx.needs_input_grad[0]) and need_dx
         dx = torch.empty(R, Kp, dtype=m.dtype, device=dev) if want_dx else None
-        maxw = max([Kp] + widths[:-1])
+        maxw = max([8, Kp] + widths[:-1])  # the library's ping-pong stride: max(8, Kp, inner widths)
         dzbuf = torch.empty(2 * R * maxw, dtype=m.dtype, device=dev) if L > 1 else None
         parts = torch.empty(_MAX_PARTS * 2 * max(widths + [Kp]), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
@@ -649,6 +649,17 @@ def _gap_row_index(n, d, q, device):
         dp = (d + q - 1) // q * q
         _gap_rows[key] = torch.cat([torch.arange(d, device=device), dp + torch.arange(n - d, device=device)])
     return _gap_rows[key]
+
+
+def ungap_rows(x, perm):
+    """Rows in the interpolate_concat column layout (perm = -D: a gap after the first D columns) ->
+    the same rows with the real columns only, in reference order."""
+    if perm >= 0:
+        return x
+    m = mode()
+    d = -perm
+    n = x.shape[1] - (m.pad(d) - d)
+    return x.index_select(1, _gap_row_index(n, d, m.q, x.device))
 
 
 class _LinearBias(torch.autograd.Function):

@@ -274,7 +274,11 @@ def test_interpolate_concat_bf16_forward_backward(rm, D1, C, k):
     feat = torch.randn(B, S, C, generator=g).cuda().to(torch.bfloat16).requires_grad_(True)
     skip = torch.randn(B * N, D1, generator=g).cuda().to(torch.bfloat16).requires_grad_(True) if D1 else None
     d2, idx = ops.three_nn(xyz1, xyz2, k)
-    rows, perm = rm.interpolate_concat(skip, feat, d2, idx)
+    rm.set_precision("bf16")
+    try:
+        rows, perm = rm.interpolate_concat(skip, feat, d2, idx)
+    finally:
+        rm.set_precision("fp32")
     dp = (D1 + 7) // 8 * 8
     assert rows.shape == (B * N, dp + C) and perm == (-D1 if D1 % 8 else 0)
     ref_feat = feat.detach().float().requires_grad_(True)

@@ -30,13 +30,13 @@ def _act(u, act):
     return F.relu(u) if act == 1 else (F.leaky_relu(u, 0.2) if act == 2 else u)
 
 
-def _near(a, b, tol=2e-5):
-    a, b = a.double(), b.double()
+def _near(a, b, tol=2e-5, atol=0.0):
+    a, b = a.detach().double(), b.detach().double()
     scale = max(float(b.abs().max()), 1e-12)
     err = float((a - b).abs().max())
-    if err > tol * scale:
+    if err > tol * scale + atol:
         print(f"_near failed: max |d| {err:.4g} vs max |b| {scale:.4g}, shape {tuple(b.shape)}")
-    return err <= tol * scale
+    return err <= tol * scale + atol
 
 
 def _first_max_pool(h, pool):
@@ -90,8 +90,10 @@ def test_f32_stack_forward_backward_vs_torch_fp64(rm, R, K, widths, act, pool, p
     assert _near(x.grad[:, :kin], xr.grad[:, :kin], 1e-4)
     for conv, w, bn, rf in zip(convs, ws, bns, refs):
         assert _near(conv.weight.grad.view_as(w), w.grad, 1e-4)
-        assert _near(bn.weight.grad, rf.weight.grad, 1e-4)
-        assert _near(bn.bias.grad, rf.bias.grad, 1e-4)
+        # (a sum that is zero in exact arithmetic -- the shift of a layer in front of another BatchNorm --
+        # comes out as rounding noise of its terms: absolute floor)
+        assert _near(bn.weight.grad, rf.weight.grad, 1e-4, atol=1e-3)
+        assert _near(bn.bias.grad, rf.bias.grad, 1e-4, atol=1e-3)
         assert float(conv.bias.grad.abs().max()) == 0.0  # exactly zero under batch statistics
         assert _near(bn.running_mean, rf.running_mean, 1e-5)
         assert _near(bn.running_var, rf.running_var, 1e-5)
@@ -113,8 +115,9 @@ def test_f32_eval_mode_uses_running_stats_and_bias(rm):
     x = torch.randn(R, K, device=dev, requires_grad=True)
     out = rm.conv_bn_act(conv, bn, x, rm.ACT_RELU)
     xr = x.detach().double().requires_grad_(True)
-    ref = F.relu(bn.double()(F.linear(xr, conv.weight.view(C, K).double(), conv.bias.double())))
-    bn.float()
+    import copy
+    bn64 = copy.deepcopy(bn).double().eval()
+    ref = F.relu(bn64(F.linear(xr, conv.weight.detach().view(C, K).double(), conv.bias.detach().double())))
     assert _near(out, ref.detach())
     out.sum().backward()
     ref.sum().backward()
@@ -131,7 +134,7 @@ def test_f32_conv_rows_bias_and_gradients(rm, R, K, n, gap):
     x = torch.randn(R, K, device=dev, requires_grad=True)
     y = rm.conv_rows(conv, x, out_gap=gap)
     xr = x.detach().double().requires_grad_(True)
-    ref = F.linear(xr, conv.weight.view(n, K).double(), conv.bias.double())
+    ref = F.linear(xr, conv.weight.detach().view(n, K).double(), conv.bias.detach().double())
     if gap:
         dp = (gap + 3) // 4 * 4
         cols = torch.cat([torch.arange(gap), dp + torch.arange(n - gap)]).to(dev)
@@ -215,7 +218,7 @@ def test_f32_group_rows_layout_and_backward(rm):
     from pointcloud_bridge_amd import ops
     torch.manual_seed(4)
     dev = "cuda"
-    B, N, S, ns, C = 2, 300, 40, 8, 13
+    B, N, S, ns, C = 2, 300, 40, 8, 14
     xyz = torch.rand(B, N, 3, device=dev)
     new_xyz = xyz[:, :S].contiguous()
     idx = torch.randint(0, N, (B, S, ns), device=dev)
@@ -225,7 +228,7 @@ def test_f32_group_rows_layout_and_backward(rm):
     assert rows.shape == (B * S * ns, kp) and perm == C and rows.dtype == torch.float32
     ref = ops.group_points(xyz, new_xyz, feat.detach(), idx).view(B * S * ns, 3 + C)  # coordinates first
     assert torch.equal(rows[:, :C], ref[:, 3:]) and torch.equal(rows[:, C:C + 3], ref[:, :3])
-    assert float(rows[:, C + 3:].abs().max()) == 0.0
+    assert kp == C + 3 or float(rows[:, C + 3:].abs().max()) == 0.0
     g = torch.randn_like(rows)
     (rows * g).sum().backward()
     want = torch.zeros(B * N, C, device=dev, dtype=torch.float64)
