@@ -543,6 +543,36 @@ int pcb_gate_bwd_bf16(const void *g, const void *x, const void *a, void *dx, voi
 int pcb_gate_bwd_f32(const void *g, const void *x, const void *a, void *dx, void *da, long n, void *stream);
 
 /*
+ * Global max-pool over the points of a scene on channels-last rows.  Replaces
+ * F.adaptive_max_pool1d(x, 1) in DGCNN.forward, models/DGCNN.py:160 (ATen: a reduction returning int64
+ * indices; in backward a zero-fill plus a scatter through them).
+ *   rows [B*N, C] (row type), out [B, C] (row type), arg [B, C] int32 = the row n attaining the maximum,
+ *   the LOWEST such row on ties; workspace: pcb_scene_max_workspace(B, C) bytes of scratch.
+ *   backward: dz[b*N + n, c] = (n == arg[b, c]) ? g[b, c] : 0, written densely (dz [B*N, C], g [B, C], row type).
+ * C % 8 == 0 (bf16) / C % 4 == 0 (fp32).
+ */
+long pcb_scene_max_workspace(int B, int C);
+/*
+ * The pooled per-scene vector joined back to the per-point rows (models/DGCNN.py:160-164: expand the
+ * pooled feature over the points and torch.cat it with the local features):
+ *   pcb_scene_concat_*  out[b*N + n, :] = [a[b*N + n, 0:C1] | g[b, 0:C2]]     (a [B*N,C1], g [B,C2], out [B*N,C1+C2])
+ *   pcb_scene_colsum_*  backward of the broadcast: out[b, c] = sum_n d[b*N + n, col0 + c] for d [B*N, ld];
+ *                       two stages through `workspace` (pcb_scene_colsum_workspace(B,N,C) bytes), fixed order,
+ *                       no atomics and no memset.
+ * (ATen runs the backward as a two-stage reduction with a semaphore buffer; captured in a hipGraph that
+ * reduction returned garbage on every replay but the first -- tools/graph_reduce_repro.py, torch-only.)
+ */
+long pcb_scene_colsum_workspace(int B, int N, int C);
+int pcb_scene_concat_bf16(const void *a, const void *g, int B, int N, int C1, int C2, void *out, void *stream);
+int pcb_scene_concat_f32(const void *a, const void *g, int B, int N, int C1, int C2, void *out, void *stream);
+int pcb_scene_colsum_bf16(const void *d, int B, int N, int ld, int col0, int C, void *out, float *workspace, void *stream);
+int pcb_scene_colsum_f32(const void *d, int B, int N, int ld, int col0, int C, void *out, float *workspace, void *stream);
+int pcb_scene_max_bf16(const void *rows, int B, int N, int C, void *out, int *arg, void *workspace, void *stream);
+int pcb_scene_max_f32(const void *rows, int B, int N, int C, void *out, int *arg, void *workspace, void *stream);
+int pcb_scene_max_bwd_bf16(const void *g, const int *arg, int B, int N, int C, void *dz, void *stream);
+int pcb_scene_max_bwd_f32(const void *g, const int *arg, int B, int N, int C, void *dz, void *stream);
+
+/*
  * A whole stack of L <= PCB_STACK_MAX_LAYERS shared-MLP layers  x -> act(BN(x W^T + b))  [-> max over
  * each `pool` consecutive rows]  enqueued from ONE call -- the loop the reference writes as
  *   for i, conv in enumerate(self.mlp_convs): new_points = F.relu(self.mlp_bns[i](conv(new_points)))

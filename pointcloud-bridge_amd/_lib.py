@@ -89,6 +89,16 @@ SIGNATURES = {
     "pcb_gate_f32": [_p, _p, _p, _l, _p],
     "pcb_gate_bwd_bf16": [_p, _p, _p, _p, _p, _l, _p],
     "pcb_gate_bwd_f32": [_p, _p, _p, _p, _p, _l, _p],
+    "pcb_scene_max_workspace": [_i, _i],
+    "pcb_scene_max_bf16": [_p, _i, _i, _i, _p, _p, _p, _p],
+    "pcb_scene_max_f32": [_p, _i, _i, _i, _p, _p, _p, _p],
+    "pcb_scene_max_bwd_bf16": [_p, _p, _i, _i, _i, _p, _p],
+    "pcb_scene_max_bwd_f32": [_p, _p, _i, _i, _i, _p, _p],
+    "pcb_scene_colsum_workspace": [_i, _i, _i],
+    "pcb_scene_concat_bf16": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "pcb_scene_concat_f32": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "pcb_scene_colsum_bf16": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_scene_colsum_f32": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
     "pcb_timer_start": [],
     "pcb_timer_enable": [_i],
     "pcb_timer_stop": [_p, _p, _p],
@@ -121,7 +131,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the build lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "pcb_status_string"
-                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems", "pcb_knn_xyz_workspace")
+                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems", "pcb_knn_xyz_workspace",
+                                                     "pcb_scene_max_workspace", "pcb_scene_colsum_workspace")
                           else ctypes.c_int)
         _lib = lib
     return _lib

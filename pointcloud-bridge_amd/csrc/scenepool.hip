@@ -1,0 +1,304 @@
+// Global max-pool over the points of a scene, on channels-last rows: DGCNN's
+//     x = F.adaptive_max_pool1d(x, 1)            (models/DGCNN.py:160, after conv5 / bn5 / LeakyReLU)
+// i.e. out[b, c] = max_n rows[b*N + n, c], and its backward dz[b*N + n, c] = (n == arg[b, c]) ? g[b, c] : 0.
+// The reference (and ATen) run it as a reduction that returns int64 indices plus, in backward, a
+// zero-fill and a scatter through those indices.  Here: one pass over the rows that folds (value, row)
+// into a sortable 64-bit key per (scene, channel) with a 64-bit atomic max -- ties go to the LOWEST row,
+// like torch.max on the CPU -- then a tiny decode; the backward is one dense write (zeros and the
+// selected gradients in the same pass), the row indices int32 and range-checked.  Both row types.
+#include "rowvec.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ unsigned sortable(float v)  // monotonic float -> unsigned
+{
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unsortable(unsigned u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// grid = (row splits, column blocks, B); block = CTb column chunks x RT row-lanes.
+// keys [B, C] u64, zeroed by the caller: hi = sortable(value), lo = ~row.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void scene_max_kernel(const uint4 *__restrict__ rows, int N, int C, int CTb,
+                                                              unsigned long long *__restrict__ keys)
+{
+    constexpr int E = RowVec<T>::E;
+    __shared__ unsigned long long red[kThreads * E];
+    const int CT = C / E;
+    const int c_chunk0 = blockIdx.y * CTb;
+    const int nch = CT - c_chunk0 < CTb ? CT - c_chunk0 : CTb;  // chunks of this block
+    const int RT = kThreads / CTb;
+    const int cc = threadIdx.x % CTb, rl = threadIdx.x / CTb;
+    const long b = blockIdx.z;
+    unsigned long long best[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) best[i] = 0ull;
+    if (cc < nch && rl < RT) {
+        const int per = (N + gridDim.x - 1) / gridDim.x;
+        const int n0 = blockIdx.x * per, n1 = n0 + per < N ? n0 + per : N;
+        for (int n = n0 + rl; n < n1; n += RT) {
+            float f[E];
+            RowVec<T>::unpack(rows[(b * N + n) * CT + c_chunk0 + cc], f);
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                // NaN: torch.max propagates it; sortable() places a positive NaN above +inf
+                const unsigned long long key = ((unsigned long long)sortable(f[i]) << 32) | (unsigned)(~n);
+                best[i] = key > best[i] ? key : best[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) red[threadIdx.x * E + i] = best[i];
+    __syncthreads();
+    // row-lanes of the block meet in LDS; one atomic per (scene, channel) and block
+    for (int o = threadIdx.x; o < nch * E; o += kThreads) {
+        const int ch = o / E, i = o % E;
+        unsigned long long m = 0ull;
+        for (int r = 0; r < RT; ++r) {
+            const unsigned long long v = red[(r * CTb + ch) * E + i];
+            m = v > m ? v : m;
+        }
+        if (m) atomicMax(&keys[b * C + (long)(c_chunk0 + ch) * E + i], m);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void scene_max_decode_kernel(const unsigned long long *__restrict__ keys, long total,
+                                                                     T *__restrict__ out, int *__restrict__ arg)
+{
+    const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= total) return;
+    const unsigned long long k = keys[e];
+    const float v = unsortable((unsigned)(k >> 32));
+    if (RowVec<T>::E == 8)   // one element in the row type (exact: the key holds a value that was read from a row)
+        reinterpret_cast<pcb_bf16 *>(out)[e] = pcb_f2bf(v);
+    else
+        reinterpret_cast<float *>(out)[e] = v;
+    arg[e] = (int)(~(unsigned)(k & 0xffffffffull));
+}
+
+// dz[b*N + n, c] = (n == arg[b, c]) ? g[b, c] : 0, one lane per 16-byte chunk of a row
+template <typename T>
+__global__ __launch_bounds__(kThreads) void scene_max_bwd_kernel(const T *__restrict__ g, const int *__restrict__ arg,
+                                                                  int N, int C, uint4 *__restrict__ dz, long nvec)
+{
+    constexpr int E = RowVec<T>::E;
+    const int CT = C / E;
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < nvec; e += (long)gridDim.x * kThreads) {
+        const int cc = (int)(e % CT);
+        const long row = e / CT;
+        const long b = row / N;
+        const int n = (int)(row - b * N);
+        float f[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const long o = b * C + (long)cc * E + i;
+            f[i] = arg[o] == n ? RowVec<T>::one(g + o) : 0.0f;
+        }
+        dz[e] = RowVec<T>::pack(f);
+    }
+}
+
+// out[b*N + n, :] = [a[b*N + n, 0:C1] | g[b, 0:C2]]: a per-scene vector broadcast to the scene's rows and
+// joined to per-point rows -- DGCNN's  torch.cat((x, local_features), dim=1)  with x the max-pooled
+// feature expanded over the points (models/DGCNN.py:160-164).  One lane per 16-byte chunk.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void scene_concat_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ g,
+                                                                 int N, int C1, int C2, uint4 *__restrict__ out, long nvec)
+{
+    constexpr int E = RowVec<T>::E;
+    const int T1 = C1 / E, T2 = C2 / E, TT = T1 + T2;
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < nvec; e += (long)gridDim.x * kThreads) {
+        const int cc = (int)(e % TT);
+        const long row = e / TT;
+        out[e] = cc < T1 ? a[row * T1 + cc] : g[(row / N) * T2 + (cc - T1)];
+    }
+}
+
+// Backward of the broadcast: dg[b, c] = sum_n d[b*N + n, col0 + c] over the scene's rows, d [B*N, ld].
+// Two stages, no atomics, no memset: grid = (row splits, column blocks, B) writes fp32 partials
+// [splits][B][C]; the second kernel adds the splits in order and stores the row type.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void scene_colsum_kernel(const T *__restrict__ d, int N, int ld, int col0, int C,
+                                                                 int CTb, float *__restrict__ part)
+{
+    constexpr int E = RowVec<T>::E;
+    __shared__ float red[kThreads * E];
+    const int CT = C / E;
+    const int c_chunk0 = blockIdx.y * CTb;
+    const int nch = CT - c_chunk0 < CTb ? CT - c_chunk0 : CTb;
+    const int RT = kThreads / CTb;
+    const int cc = threadIdx.x % CTb, rl = threadIdx.x / CTb;
+    const long b = blockIdx.z;
+    float s[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) s[i] = 0.0f;
+    if (cc < nch && rl < RT) {
+        const int per = (N + gridDim.x - 1) / gridDim.x;
+        const int n0 = blockIdx.x * per, n1 = n0 + per < N ? n0 + per : N;
+        for (int n = n0 + rl; n < n1; n += RT) {
+            float f[E];
+            RowVec<T>::unpack(*reinterpret_cast<const uint4 *>(d + (b * N + n) * (long)ld + col0 + (long)(c_chunk0 + cc) * E), f);
+#pragma unroll
+            for (int i = 0; i < E; ++i) s[i] += f[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) red[threadIdx.x * E + i] = s[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < nch * E; o += kThreads) {
+        const int ch = o / E, i = o % E;
+        float t = 0.0f;
+        for (int r = 0; r < RT; ++r) t += red[(r * CTb + ch) * E + i];
+        part[((long)blockIdx.x * gridDim.z + b) * C + (long)(c_chunk0 + ch) * E + i] = t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void scene_colsum_final_kernel(const float *__restrict__ part, int splits, long total,
+                                                                       T *__restrict__ out)
+{
+    const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= total) return;
+    float t = 0.0f;
+    for (int s = 0; s < splits; ++s) t += part[(long)s * total + e];
+    if (RowVec<T>::E == 8)
+        reinterpret_cast<pcb_bf16 *>(out)[e] = pcb_f2bf(t);
+    else
+        reinterpret_cast<float *>(out)[e] = t;
+}
+
+inline int colsum_splits(int B, int N, int C, int E)
+{
+    const int CT = C / E;
+    const int CTb = CT < 32 ? CT : 32;
+    const int RT = kThreads / CTb;
+    int splits = (N + 8 * RT - 1) / (8 * RT);
+    const int want = 1024 / (((CT + CTb - 1) / CTb) * B);
+    if (splits > want) splits = want;
+    return splits < 1 ? 1 : splits;
+}
+
+template <typename T>
+int scene_concat(const void *a, const void *g, int B, int N, int C1, int C2, void *out, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (!a || !g || !out || B <= 0 || N <= 0 || C1 <= 0 || C2 <= 0) return PCB_ERR_INVALID_ARG;
+    if ((C1 % E) || (C2 % E)) return PCB_ERR_UNSUPPORTED;
+    const long nvec = (long)B * N * ((C1 + C2) / E);
+    long blocks = (nvec + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scene_concat_kernel<T>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4 *)a, (const uint4 *)g, N, C1, C2, (uint4 *)out, nvec);
+    return pcb_check_launch();
+}
+
+template <typename T>
+int scene_colsum(const void *d, int B, int N, int ld, int col0, int C, void *out, float *workspace, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (!d || !out || !workspace || B <= 0 || N <= 0 || C <= 0 || col0 < 0 || col0 + C > ld) return PCB_ERR_INVALID_ARG;
+    if ((C % E) || (ld % E) || (col0 % E)) return PCB_ERR_UNSUPPORTED;
+    const int CT = C / E;
+    const int CTb = CT < 32 ? CT : 32;
+    const int splits = colsum_splits(B, N, C, E);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(scene_colsum_kernel<T>, dim3(splits, (CT + CTb - 1) / CTb, B), dim3(kThreads), 0, st, (const T *)d, N,
+                       ld, col0, C, CTb, workspace);
+    const long total = (long)B * C;
+    hipLaunchKernelGGL(scene_colsum_final_kernel<T>, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                       workspace, splits, total, (T *)out);
+    return pcb_check_launch();
+}
+
+template <typename T>
+int scene_max(const void *rows, int B, int N, int C, void *out, int *arg, void *workspace, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (!rows || !out || !arg || !workspace || B <= 0 || N <= 0 || C <= 0) return PCB_ERR_INVALID_ARG;
+    if (C % E) return PCB_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *keys = (unsigned long long *)workspace;
+    if (hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)B * C, st) != hipSuccess) return PCB_ERR_LAUNCH;
+    const int CT = C / E;
+    const int CTb = CT < 32 ? CT : 32;                    // column chunks per block
+    const int RT = kThreads / CTb;
+    int splits = (N + 8 * RT - 1) / (8 * RT);             // at least 8 rows per row-lane
+    const int want = 1024 / (((CT + CTb - 1) / CTb) * B);  // about 1024 blocks in all
+    if (splits > want) splits = want;
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(scene_max_kernel<T>, dim3(splits, (CT + CTb - 1) / CTb, B), dim3(kThreads), 0, st,
+                       (const uint4 *)rows, N, C, CTb, keys);
+    const long total = (long)B * C;
+    hipLaunchKernelGGL(scene_max_decode_kernel<T>, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                       keys, total, (T *)out, arg);
+    return pcb_check_launch();
+}
+
+template <typename T>
+int scene_max_bwd(const void *g, const int *arg, int B, int N, int C, void *dz, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (!g || !arg || !dz || B <= 0 || N <= 0 || C <= 0) return PCB_ERR_INVALID_ARG;
+    if (C % E) return PCB_ERR_UNSUPPORTED;
+    const long nvec = (long)B * N * (C / E);
+    long blocks = (nvec + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scene_max_bwd_kernel<T>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, (const T *)g,
+                       arg, N, C, (uint4 *)dz, nvec);
+    return pcb_check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+long pcb_scene_max_workspace(int B, int C) { return (B <= 0 || C <= 0) ? 0 : 8L * B * C; }
+
+long pcb_scene_colsum_workspace(int B, int N, int C)
+{
+    if (B <= 0 || N <= 0 || C <= 0 || (C & 3)) return 0;
+    const int s4 = colsum_splits(B, N, C, 4), s8 = (C & 7) ? 0 : colsum_splits(B, N, C, 8);
+    return 4L * (s4 > s8 ? s4 : s8) * B * C;  // enough for either row type
+}
+int pcb_scene_concat_bf16(const void *a, const void *g, int B, int N, int C1, int C2, void *out, void *stream)
+{
+    return scene_concat<pcb_bf16>(a, g, B, N, C1, C2, out, stream);
+}
+int pcb_scene_concat_f32(const void *a, const void *g, int B, int N, int C1, int C2, void *out, void *stream)
+{
+    return scene_concat<float>(a, g, B, N, C1, C2, out, stream);
+}
+int pcb_scene_colsum_bf16(const void *d, int B, int N, int ld, int col0, int C, void *out, float *workspace, void *stream)
+{
+    return scene_colsum<pcb_bf16>(d, B, N, ld, col0, C, out, workspace, stream);
+}
+int pcb_scene_colsum_f32(const void *d, int B, int N, int ld, int col0, int C, void *out, float *workspace, void *stream)
+{
+    return scene_colsum<float>(d, B, N, ld, col0, C, out, workspace, stream);
+}
+
+int pcb_scene_max_bf16(const void *rows, int B, int N, int C, void *out, int *arg, void *workspace, void *stream)
+{
+    return scene_max<pcb_bf16>(rows, B, N, C, out, arg, workspace, stream);
+}
+int pcb_scene_max_f32(const void *rows, int B, int N, int C, void *out, int *arg, void *workspace, void *stream)
+{
+    return scene_max<float>(rows, B, N, C, out, arg, workspace, stream);
+}
+int pcb_scene_max_bwd_bf16(const void *g, const int *arg, int B, int N, int C, void *dz, void *stream)
+{
+    return scene_max_bwd<pcb_bf16>(g, arg, B, N, C, dz, stream);
+}
+int pcb_scene_max_bwd_f32(const void *g, const int *arg, int B, int N, int C, void *dz, void *stream)
+{
+    return scene_max_bwd<float>(g, arg, B, N, C, dz, stream);
+}
+
+}  // extern "C"

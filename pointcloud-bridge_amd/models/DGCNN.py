@@ -124,8 +124,8 @@ class DGCNN(nn.Module):
         local = torch.cat((x1, x2, x3, x4), dim=2).view(B * N, 320)
         local_norm = rowmlp.bn_act_rows(self.local_bn, local, rowmlp.ACT_LEAKY)
         g = rowmlp.conv_bn_act(self.conv5[0], self.conv5[1], local, rowmlp.ACT_LEAKY)
-        g = g.view(B, N, 1024).max(dim=1, keepdim=True)[0]  # adaptive_max_pool1d(x, 1), :160
-        pf = torch.cat([local_norm.view(B, N, 320), g.expand(-1, N, -1)], dim=2).view(B * N, 1344)
+        g = rowmlp.scene_max(g, B, N)                         # adaptive_max_pool1d(x, 1), :160
+        pf = rowmlp.scene_concat(local_norm, g, B, N)        # [local | pooled], :163-164  -> [B*N, 1344]
         pc = self.point_conv
         pf = rowmlp.conv_bn_act(pc[0], pc[1], pf, rowmlp.ACT_LEAKY)
         pf = rowmlp.conv_bn_act(pc[3], pc[4], pf, rowmlp.ACT_LEAKY)

@@ -888,6 +888,76 @@ def gate_rows(x, a):
     return x * torch.sigmoid(a)
 
 
+class _SceneMax(torch.autograd.Function):
+    """max over the N rows of every scene (DGCNN's adaptive_max_pool1d, models/DGCNN.py:160) with own
+    kernels (csrc/scenepool.hip): int32 row indices, a dense one-pass backward."""
+
+    @staticmethod
+    def forward(ctx, rows, B, N, m):
+        C = rows.shape[1]
+        dev = rows.device
+        out = torch.empty(B, C, dtype=m.dtype, device=dev)
+        arg = torch.empty(B, C, dtype=torch.int32, device=dev)
+        ws = torch.empty(_lib.load().pcb_scene_max_workspace(B, C), dtype=torch.uint8, device=dev)
+        with on_device(dev):
+            _launch("pcb_scene_max_" + m.sfx, B * N * C, rows.data_ptr(), B, N, C, out.data_ptr(), arg.data_ptr(), ws.data_ptr())
+        ctx.save_for_backward(arg)
+        ctx.cfg = (B, N, C, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        B, N, C, m = ctx.cfg
+        g = g.to(m.dtype).contiguous()
+        dz = torch.empty(B * N, C, dtype=m.dtype, device=g.device)
+        with on_device(g.device):
+            _launch("pcb_scene_max_bwd_" + m.sfx, B * N * C, g.data_ptr(), arg.data_ptr(), B, N, C, dz.data_ptr())
+        return dz, None, None, None
+
+
+def scene_max(rows, B, N):
+    """rows [B*N, C] -> [B, C]: the maximum over the N rows of each scene (ties: lowest row)."""
+    m = mode()
+    if rows.shape[1] % m.q:
+        return rows.view(B, N, -1).max(dim=1)[0]
+    return _SceneMax.apply(rows.to(m.dtype).contiguous(), B, N, m)
+
+
+class _SceneConcat(torch.autograd.Function):
+    """[a | g broadcast over the scene's rows] with own kernels in both directions (csrc/scenepool.hip)."""
+
+    @staticmethod
+    def forward(ctx, a, g, B, N, m):
+        C1, C2 = a.shape[1], g.shape[1]
+        out = torch.empty(B * N, C1 + C2, dtype=m.dtype, device=a.device)
+        with on_device(a.device):
+            _launch("pcb_scene_concat_" + m.sfx, B * N * (C1 + C2), a.data_ptr(), g.data_ptr(), B, N, C1, C2, out.data_ptr())
+        ctx.cfg = (B, N, C1, C2, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        B, N, C1, C2, m = ctx.cfg
+        d = d.to(m.dtype).contiguous()
+        dg = None
+        if ctx.needs_input_grad[1]:
+            dg = torch.empty(B, C2, dtype=m.dtype, device=d.device)
+            ws = torch.empty(_lib.load().pcb_scene_colsum_workspace(B, N, C2), dtype=torch.uint8, device=d.device)
+            with on_device(d.device):
+                _launch("pcb_scene_colsum_" + m.sfx, B * N * C2, d.data_ptr(), B, N, C1 + C2, C1, C2, dg.data_ptr(), ws.data_ptr())
+        return (d[:, :C1] if ctx.needs_input_grad[0] else None), dg, None, None, None
+
+
+def scene_concat(a_rows, g, B, N):
+    """a_rows [B*N, C1], g [B, C2] -> [B*N, C1+C2]: every row of scene b followed by g[b]
+    (DGCNN.py:160-164: the pooled feature expanded over the points and concatenated)."""
+    m = mode()
+    if a_rows.shape[1] % m.q or g.shape[1] % m.q:
+        return torch.cat([a_rows.view(B, N, -1), g.view(B, 1, -1).expand(-1, N, -1).to(a_rows.dtype)], dim=2).view(B * N, -1)
+    return _SceneConcat.apply(a_rows.to(m.dtype).contiguous(), g.to(m.dtype).contiguous(), B, N, m)
+
+
 def bn_act_rows(bn, x, act=ACT_NONE):
     """BatchNorm (+ activation) on rows without a preceding conv (DGCNN.local_bn)."""
     m = mode()

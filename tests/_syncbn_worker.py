@@ -1,0 +1,81 @@
+"""Child process of tests/test_gpu_round2.py::test_syncbatchnorm_two_ranks_equal_one_rank_global_batch.
+
+Started twice by torch.distributed.run (gloo; both ranks share cuda:0).  Each rank runs a fused MLP
+stack with nn.SyncBatchNorm layers on ITS half of the rows; rank 0 also runs the same stack with
+plain BatchNorm on ALL rows in one process.  SURVEY section 8(e): with the statistics all-reduced a
+G-rank step must equal the single-process step over the global batch -- outputs of the own rows,
+input gradients of the own rows, parameter gradients after the gradient all-reduce (mean over ranks
+of the local gradients of loss_r = global-mean loss restricted to the shard, times G), running
+statistics.  Writes "OK <max errors>" or the failure to the path given as argv[1].
+"""
+import copy
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main(out_path, precision):
+    from pointcloud_bridge_amd import parallel, rowmlp
+    rank, world, _ = parallel.init_from_env("gloo")
+    assert world == 2
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    rowmlp.set_precision(precision)
+    m = rowmlp.mode()
+    torch.manual_seed(3)
+    R, K, widths, pool = 4096, 24, [32, 64, 64], 16      # R rows per rank
+    convs = nn.ModuleList(nn.Conv2d(a, b, 1) for a, b in zip([K] + widths[:-1], widths)).to(dev)
+    bns = nn.ModuleList(nn.BatchNorm2d(b) for b in widths).to(dev).train()
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    x_all = torch.randn(world * R, K, device=dev).to(m.dtype)
+    g_all = torch.randn(world * R // pool, widths[-1], device=dev)
+    sync_bns = nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(bns))
+    sync_convs = copy.deepcopy(convs)
+
+    x = x_all[rank * R:(rank + 1) * R].clone().requires_grad_(True)
+    out = rowmlp.mlp_rows(sync_convs, sync_bns, x, pool=pool)
+    go = g_all[rank * (R // pool):(rank + 1) * (R // pool)]
+    (out.float() * go).sum().backward()
+    params = [p for mod in (sync_convs, sync_bns) for p in mod.parameters()]
+    bucket = parallel.FlatGradAllReduce(params, assign_views=False)
+    bucket.reduce()  # mean over ranks of the local gradients
+    flat_sync = bucket.flat * world  # sum over ranks == gradient of the global sum-loss
+
+    msg = "OK"
+    if rank == 0:
+        xf = x_all.clone().requires_grad_(True)
+        ref = rowmlp.mlp_rows(convs, bns, xf, pool=pool)
+        (ref.float() * g_all).sum().backward()
+        flat_ref = torch.cat([p.grad.reshape(-1) for mod in (convs, bns) for p in mod.parameters()])
+        tol = 3e-2 if precision == "bf16" else 2e-4
+
+        def err(a, b):
+            return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6))
+
+        e_out = err(out, ref[:R // pool])
+        e_dx = err(x.grad, xf.grad[:R])
+        e_par = err(flat_sync, flat_ref)
+        e_rm = max(err(a.running_mean, b.running_mean) for a, b in zip(sync_bns, bns))
+        e_rv = max(err(a.running_var, b.running_var) for a, b in zip(sync_bns, bns))
+        nbt = all(int(a.num_batches_tracked) == 1 for a in sync_bns)
+        ok = e_out < tol and e_dx < tol and e_par < tol and e_rm < 1e-3 and e_rv < 1e-3 and nbt
+        msg = f"{'OK' if ok else 'FAIL'} out {e_out:.2e} dx {e_dx:.2e} params {e_par:.2e} rmean {e_rm:.2e} rvar {e_rv:.2e} nbt {nbt}"
+        with open(out_path, "a") as f:
+            f.write(f"{precision}: {msg}\n")
+    dist.barrier()
+    return msg
+
+
+if __name__ == "__main__":
+    for prec in ("fp32", "bf16"):
+        main(sys.argv[1], prec)
+    dist.destroy_process_group()

@@ -80,3 +80,51 @@ def test_missing_library_fails_loudly(lib, monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libpcb_hip.so")
     with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
         lib.load()
+
+
+REF = "/root/reference/Highway_bridge"
+_DUMP = r'''
+import hashlib, json, sys
+import torch
+REPO, REF, dropin = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+import models                                   # the reference's package (empty __init__)
+if dropin:                                      # what INTEGRATION.md section 2 tells a maintainer to do
+    from pointcloud_bridge_amd.models import pointnet2_utils as drop
+    sys.modules["models.pointnet2_utils"] = drop
+    models.pointnet2_utils = drop
+from models.model import EnhancedPointNet2, PointNet2          # the reference's containers, unchanged
+from models.pointnet2 import PointNet2 as PointNet2Skip
+out = {}
+for name, ctor in (("ssg", lambda: PointNet2(5)), ("ssg_skip", lambda: PointNet2Skip(5)), ("bridgeseg", lambda: EnhancedPointNet2(5))):
+    torch.manual_seed(42)
+    sd = ctor().state_dict()
+    out[name] = [(k, list(v.shape), hashlib.sha1(v.detach().cpu().numpy().tobytes()).hexdigest()) for k, v in sd.items()]
+if dropin:
+    import models.model as mm
+    assert mm.SetAbstraction.__module__.startswith("pointcloud_bridge_amd"), mm.SetAbstraction.__module__
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
+def test_reference_containers_build_unchanged_on_the_dropin(lib):
+    """INTEGRATION.md section 2, exercised: the reference's own containers (models/model.py:12-147,
+    models/pointnet2.py:10-61) imported over the drop-in `pointnet2_utils` construct the same networks --
+    same state_dict keys, shapes and (same seed) parameter values -- as over the reference's module."""
+    import json
+    import subprocess
+    import sys
+    res = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", _DUMP, REPO, REF, flag], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    ref, mine = res
+    for name in ref:
+        assert [k for k, _, _ in mine[name]] == [k for k, _, _ in ref[name]], name
+        assert mine[name] == ref[name], f"{name}: parameter shapes or seeded values differ"
+    assert len(ref["bridgeseg"]) > 300

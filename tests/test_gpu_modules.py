@@ -177,13 +177,15 @@ def test_dgcnn_logit_parity(k):
     model = build(DGCNN, g["init_seed"], 5, k=k)
     le, lt, loss = run_seg(model, dev(g["xyz"]), dev(g["colors"]), dev(g["labels"]), int(g["fwd_seed"]), 2)
     assert tuple(le.shape) == g[f"k{k}_logits_eval"].shape  # [B, N, classes]
-    # The graph is rebuilt in 64-d feature space three times: a neighbour pair whose distances differ
-    # in the last bits may swap against the reference's blocked sgemm, which moves a few points' logits.
-    for got, ref in ((le, g[f"k{k}_logits_eval"]), (lt, g[f"k{k}_logits_train"])):
-        diff = np.abs(got.detach().cpu().numpy() - ref) / np.abs(ref).max()
-        assert np.mean(diff < REL) > 0.995, f"only {np.mean(diff < REL):.4f} of logits within 1e-4"
-        assert diff.max() < 5e-2
-    assert abs(loss - float(g[f"k{k}_loss"])) < 1e-3 * abs(float(g[f"k{k}_loss"]))
+    # The graph is rebuilt in 64-d feature space three times.  With the MLPs on the exact fp32 matrix
+    # cores every logit of this fixture is within 1e-4 (measured 1.4e-6 eval, 6e-6 train; round 1,
+    # with library GEMMs in front of the kNN, had neighbour swaps at last-bit ties move single points
+    # by up to 5e-2).  A swap at an exact tie remains possible on other inputs: tests/test_gpu_ops.py
+    # pins the kNN itself, tie-tolerantly.
+    assert rel_err(le, g[f"k{k}_logits_eval"]) < REL
+    assert rel_err(lt, g[f"k{k}_logits_train"]) < REL
+    assert abs(loss - float(g[f"k{k}_loss"])) < 1e-5 * abs(float(g[f"k{k}_loss"]))
+    assert_grad_norms(grad_norms(model), g[f"k{k}_grad_norms"], 5e-3)
 
 
 def test_sampling_prefetch_gives_identical_results(mpu):

@@ -1,0 +1,288 @@
+"""GPU: parity cases added in round 2.
+
+  * sample_and_group against the reference's own output (direct golden)
+  * the reference training loop's losses over several Adam steps (row H1)
+  * bf16 networks against the REFERENCE fixtures, with bars set from measured errors
+  * a captured (hipGraph) DGCNN step against the eager step
+  * the eval-mode operand cache under FlatAdam steps and library-side running-statistics updates
+  * prefetched results are not inherited by a new tensor that lands at a dropped batch's address
+  * SyncBatchNorm in the fused engine: two ranks == one rank over the global batch (both row types)
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tests.helpers import load_golden
+from tests.test_gpu_modules import assert_grad_norms, build, dev, dropout_eval, grad_norms, rel_err, run_seg
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tag", ["cont", "grid"])
+def test_sample_and_group_golden(tag):
+    """sample_and_group (reference :42-60): FPS + ball query + grouping; new_xyz bitwise, new_points exact
+    (coordinates first, then the features), with and without features; same CPU-generator draw."""
+    from pointcloud_bridge_amd.models import pointnet2_utils as mpu
+    g = load_golden("sample_and_group")
+    xyz, pts = dev(g[f"{tag}_xyz"]), dev(g["points"])
+    args = (int(g["npoint"]), float(g["radius"]), int(g["nsample"]))
+    torch.manual_seed(int(g["fwd_seed"]))
+    new_xyz, new_points = mpu.sample_and_group(*args, xyz, pts)
+    assert np.array_equal(new_xyz.cpu().numpy(), g[f"{tag}_new_xyz"])
+    assert np.array_equal(new_points.cpu().numpy(), g[f"{tag}_new_points"])
+    torch.manual_seed(int(g["fwd_seed"]))
+    new_xyz0, new_points0 = mpu.sample_and_group(*args, xyz, None)
+    assert np.array_equal(new_xyz0.cpu().numpy(), g[f"{tag}_new_xyz"])
+    assert np.array_equal(new_points0.cpu().numpy(), g[f"{tag}_new_points_nofeat"])
+
+
+def test_training_steps_follow_the_reference_loop():
+    """Row H1: the reference's PointNet2 under the reference loop's Adam + CrossEntropy for 4 steps over
+    two batches (tests/golden/make_golden_round2.py).  The build's network on the HIP path (fp32 rows)
+    must follow the same trajectory.  The first loss (no update yet) matches to 1e-5.  From there on
+    Adam's first updates are sign-like -- lr * g / (|g| + 1e-8) -- so entries whose gradient is
+    rounding noise (1e-8 and below: e.g. the conv biases in front of a BatchNorm, exactly 0.0 here and
+    1e-9-sized noise in the reference) move by up to lr in directions that differ between any two
+    implementations; measured on MI355X: 1.1e-4, 1.2e-3, 1.8e-3 relative on the losses of steps 2-4.
+    Bars: 5e-3 on the losses, 5e-2 of the logit range after the last step."""
+    from pointcloud_bridge_amd.models.containers import PointNet2
+    g = load_golden("train_steps")
+    model = build(PointNet2, g["init_seed"], 5)
+    model.train()
+    dropout_eval(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    batches = [(dev(g[f"xyz{i}"]), dev(g[f"colors{i}"]), dev(g[f"labels{i}"])) for i in range(2)]
+    torch.manual_seed(int(g["fwd_seed"]))
+    losses = []
+    for i in range(int(g["steps"])):
+        xyz, colors, labels = batches[i % 2]
+        opt.zero_grad()
+        loss = F.cross_entropy(model(xyz, colors), labels)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print("losses", losses, "reference", g["losses"].tolist())
+    assert abs(losses[0] - g["losses"][0]) < 1e-5 * g["losses"][0]
+    np.testing.assert_allclose(losses, g["losses"], rtol=5e-3)
+    assert losses[-1] < losses[0] - 0.1   # it learns, as the reference does (1.626 -> 1.442)
+    model.eval()
+    with torch.no_grad():
+        final = model(batches[0][0], batches[0][1])
+    print("final logits rel err", rel_err(final, g["final_logits_eval"]))
+    assert rel_err(final, g["final_logits_eval"]) < 5e-2
+
+
+# Measured on MI355X (tools/bf16_parity.py, round 2): bf16 rows against the REFERENCE's fp32 outputs
+# (relative: max |d| / max |ref| and mean |d| / mean |ref| for logits).
+#   name            eval max / mean       train max / mean      loss      grad norms median / max
+#   pn2_ssg         4.8e-3 / 1.6e-3       1.48e-1 / 1.64e-1     1.1e-3    2.1e-2 / 0.25
+#   pn2_ssg_skip    4.7e-3 / 2.0e-3       1.08e-1 / 1.46e-1     1.5e-4    1.6e-2 / 0.20
+#   pn2_msg         5.6e-3 / 2.0e-3       1.53e-1 / 1.34e-1     8.7e-4    2.1e-2 / 0.31
+# Eval mode is bf16 rounding noise (2^-9 per stored activation).  Train mode is ~50x worse, and
+# tools/bf16_stage_err.py shows why: the error grows layer by layer (sa1 0.8 % ... fp1 11 %) because a
+# stored pre-BatchNorm value y carries an absolute error of 2^-9 |y| while BatchNorm with BATCH
+# statistics divides by std(y): the error in units of the normalised signal is 2^-9 (|mean|/std + 1)
+# per layer, and |mean|/std is 1.5-9 over these layers (in eval mode the running variance of a fresh
+# network is ~1, so nothing is amplified).  The loss and the gradient norms stay close because the
+# error is a smooth per-point perturbation.  Bars = about twice the measured values.
+_BF16_BARS = {
+    "model_pn2_ssg": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=5e-2, gn_max=0.6),
+    "model_pn2_ssg_skip": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=5e-2, gn_max=0.6),
+    "model_pn2_msg": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=5e-2, gn_max=0.6),
+}
+
+
+def _bf16_errors(name, kw):
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models import containers
+    g = load_golden(name)
+    kw = dict(kw)
+    cls = getattr(containers, kw.pop("cls"))
+    model = build(cls, g["init_seed"], 5, **kw)
+    rowmlp.set_precision("bf16")
+    try:
+        le, lt, loss = run_seg(model, dev(g["xyz"]), dev(g["colors"]), dev(g["labels"]), int(g["fwd_seed"]), 1)
+    finally:
+        rowmlp.set_precision("fp32")
+    out = {}
+    for tag, got, ref in (("eval", le, g["logits_eval"]), ("train", lt, g["logits_train"])):
+        d = np.abs(got.float().detach().cpu().numpy() - ref)
+        out[f"{tag}_max"] = float(d.max() / np.abs(ref).max())
+        out[f"{tag}_mean"] = float(d.mean() / np.abs(ref).mean())
+    out["loss"] = abs(loss - float(g["loss"])) / abs(float(g["loss"]))
+    gn, ref = grad_norms(model), g["grad_norms"]
+    big = ref > 1e-3 * ref.max()   # biases in front of a BatchNorm: zero in exact arithmetic
+    r = np.abs(gn[big] - ref[big]) / ref[big]
+    out["gn_median"], out["gn_max"] = float(np.median(r)), float(r.max())
+    return out
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("model_pn2_ssg", dict(cls="PointNet2", rgb_skip=False)),
+    ("model_pn2_ssg_skip", dict(cls="PointNet2", rgb_skip=True)),
+    ("model_pn2_msg", dict(cls="PointNet2MSG")),
+])
+def test_bf16_networks_against_reference_fixtures(name, kw):
+    """The arithmetic bench.py times (bf16 rows) against the reference's own fp32 outputs: eval and
+    train logits, loss, per-parameter gradient norms.  Same sampling (fp32 geometry), so the differences
+    are bf16 rounding of the activations only."""
+    e = _bf16_errors(name, kw)
+    bars = _BF16_BARS[name]
+    print(name, {k: f"{v:.3e}" for k, v in e.items()})
+    for key, bar in bars.items():
+        assert e[key] < bar, (key, e[key], bar)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 8e-2)])
+def test_dgcnn_captured_step_equals_eager_step(precision, tol):
+    """A DGCNN training step (forward + CrossEntropy + backward: grid kNN + three feature-space kNN
+    graphs, EdgeConv blocks, global max-pool, head) captured into ONE hipGraph must give the eager
+    step's loss and gradients -- on a first replay AND on replays that follow ordinary host-side
+    allocator activity.  Round 1 refused --graph for DGCNN after a replay ended in a GPU memory fault.
+    The fault is reproducible (tools/dgcnn_repro.py): back-to-back replays are clean; a replay after
+    ordinary tensor allocations died in ATen's scatter kernel -- the backward of the
+    `x.max(dim=1)` global pool, the only consumer of an UNCLAMPED index tensor in the step (every own
+    kernel clamps its indices).  The pool is now csrc/scenepool.hip (int32 row indices compared, never
+    dereferenced).  Tolerances: fp32 rows 2e-4 (fp32 atomics reorder sums); bf16 rows 8e-2 -- two EAGER
+    bf16 steps differ by 2e-2 on the BatchNorm gradients of the first blocks (atomic order -> bf16
+    rounding of the scattered gradients), measured with the same tool."""
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models.DGCNN import DGCNN
+    g = load_golden("model_dgcnn")
+    xyz, colors, labels = dev(g["xyz"]), dev(g["colors"]), dev(g["labels"])
+    model = build(DGCNN, g["init_seed"], 5, k=20).train()
+    rowmlp.set_precision(precision)
+    try:
+        def step():
+            loss = F.cross_entropy(model(xyz, colors).reshape(-1, 5), labels.reshape(-1))
+            loss.backward()
+            return loss
+
+        for p in model.parameters():
+            p.grad = None
+        eager_loss = float(step())
+        eager = [p.grad.clone() for p in model.parameters()]
+        gmax = max(float(t.abs().max()) for t in eager)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for p in model.parameters():
+                p.grad = None
+            step()   # warm-up on a side stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in model.parameters():
+            p.grad = None
+        loss_buf = torch.zeros((), device="cuda")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss_buf.copy_(step().detach())
+        for replay in range(3):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert abs(float(loss_buf) - eager_loss) < 1e-3 * abs(eager_loss)
+            for a, b in zip([p.grad for p in model.parameters()], eager):
+                # the comparison itself is the host-side allocator activity in front of the next replay
+                # (gradients that are zero in exact arithmetic -- bn5.bias behind the pool and the next
+                # BatchNorm -- are rounding noise on both sides: floor at 1 % of the largest gradient)
+                assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-2 * gmax), replay
+            junk = [torch.randn(257, 1031, device="cuda") for _ in range(8)]  # more churn: fresh blocks, written
+            del junk
+    finally:
+        rowmlp.set_precision("fp32")
+
+
+def test_eval_cache_sees_flat_adam_steps_and_running_stat_updates():
+    """the eval-mode operand cache must not serve stale weights after parallel.FlatAdam
+    stepped the flat buffer the parameters are views of, nor stale BatchNorm constants after a
+    training-mode forward updated the running statistics inside the library (neither bumps a tensor
+    version counter)."""
+    from pointcloud_bridge_amd import parallel, rowmlp
+    from pointcloud_bridge_amd.models.containers import PointNet2
+    torch.manual_seed(1)
+    model = PointNet2(5).cuda()
+    B, N = 2, 1024
+    xyz = torch.rand(B, N, 3, device="cuda")
+    col = torch.rand(B, N, 3, device="cuda")
+    lab = torch.randint(0, 5, (B, N), device="cuda")
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = parallel.FlatAdam(params, lr=1e-2)
+
+    def evaluate():
+        model.eval()
+        with torch.no_grad():
+            torch.manual_seed(5)
+            return model(xyz, col).float().clone()
+
+    for precision in ("bf16", "fp32"):
+        rowmlp.set_precision(precision)
+        try:
+            first = evaluate()
+            assert torch.equal(first, evaluate())           # cached operands: identical
+            model.train()
+            for p in params:
+                p.grad = None
+            torch.manual_seed(5)
+            F.cross_entropy(model(xyz, col), lab).backward()  # updates running statistics in the library
+            opt.step()                                        # updates the parameters through the flat buffer
+            after = evaluate()
+            assert not torch.equal(first, after), "eval output unchanged after a training step: stale cache"
+            rowmlp._eval_operands.clear()
+            assert torch.equal(after, evaluate()), "cached eval differs from a freshly prepared one"
+        finally:
+            rowmlp.set_precision("fp32")
+
+
+def test_prefetch_is_not_inherited_by_a_new_tensor_at_the_same_address():
+    """prefetch(A); A is dropped without being forwarded; B (same shape) lands at
+    A's address.  B's forward must equal the non-prefetched result -- for the PointNet++ pyramid, the
+    DGCNN coordinate graph and the bridge geometry."""
+    from pointcloud_bridge_amd.models import pointnet2_utils as mpu
+    from pointcloud_bridge_amd.models.containers import EnhancedPointNet2, PointNet2MSG
+    from pointcloud_bridge_amd.models.DGCNN import DGCNN
+    torch.manual_seed(2)
+    B, N = 2, 1100   # an unusual size: the freed block is the allocator's exact fit for the next request
+    col = torch.rand(B, N, 3, device="cuda")
+    for make in (lambda: PointNet2MSG(5), lambda: DGCNN(5, k=8), lambda: EnhancedPointNet2(5)):
+        torch.manual_seed(3)
+        model = make().cuda().eval()
+        torch.cuda.synchronize()
+        a = torch.rand(B, N, 3, device="cuda")
+        ptr = a.data_ptr()
+        with torch.no_grad():
+            torch.manual_seed(9)
+            model.prefetch(a)
+            torch.cuda.synchronize()
+            del a                                   # dropped without a forward pass
+            b = torch.rand(B, N, 3, device="cuda")  # the caching allocator hands out A's block again
+            if b.data_ptr() != ptr:
+                pytest.skip("allocator did not reuse the block: the hazard cannot be staged here")
+            torch.manual_seed(11)
+            got = model(b, col)
+            mpu._prefetched.clear()
+            mpu._parked.clear()
+            torch.manual_seed(11)
+            want = model(b, col)
+        assert torch.equal(got, want), type(model).__name__
+
+
+def test_syncbatchnorm_two_ranks_equal_one_rank_global_batch(tmp_path):
+    """SyncBatchNorm in the fused engine.  Two ranks (gloo, sharing this GPU; the launcher
+    is a fresh child process started before anything here touches the device in it) each run a stack
+    on half of the rows; rank 0 compares with the single-process stack over all rows."""
+    out = tmp_path / "syncbn.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29653", os.path.join(REPO, "tests", "_syncbn_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = out.read_text().strip().splitlines()
+    assert len(lines) == 2 and all(": OK" in ln for ln in lines), lines
