@@ -6,13 +6,18 @@ PointNet++ segmentation network on synthetic clouds, B=16 scenes x N=16384 point
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus 8 --steps 20 --warmup 5
 
-One process per GPU; scenes are sharded (weak scaling: B scenes per GPU); the only collective is
-one flat gradient all-reduce over RCCL.  Rank 0 prints ONE JSON line (contract in the task brief).
+One process per GPU; scenes are sharded (weak scaling: B scenes per GPU; --scaling strong: ONE global
+batch of B scenes split over the ranks); the only data-path collective is the flat gradient
+all-reduce over RCCL, started bucket by bucket while the backward pass is still running.  Rank 0
+prints ONE JSON line (contract in the task brief).
 `roofline` is measured live with HIP events around the launches of the dominant HBM-bound kernel
-inside the timed region; `cpu_baseline` times the ATen port of the reference's CPU path
-(oracle/torch_port.py) on this host's cores over a bounded sample (rank 0, N=1 only).
+inside the timed region; `roofline.whole_step` is the algorithmic traffic of EVERY launch of the
+library over the step time, with the FPS chain's time as a separate latency term; `cpu_baseline`
+times the ATen port of the reference's CPU path (oracle/torch_port.py) on this host's cores over a
+bounded sample (rank 0, N=1 only); `extra` (N=1 only) carries short runs of the other configurations.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -29,16 +34,42 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def synthetic_batch(B, N, seed, device):
-    """Unit-ball clouds normalised like utils/simpdataset.py:47-62, colours U[0,1), labels 0..4."""
-    g = torch.Generator().manual_seed(seed)
-    v = torch.randn(B, N, 3, generator=g)
-    p = v / v.norm(dim=-1, keepdim=True) * torch.rand(B, N, 1, generator=g) ** (1.0 / 3.0)
+def _normalise(p):
+    """Centre and scale to the unit ball exactly like utils/simpdataset.py:47-62."""
     p = p - p.mean(dim=1, keepdim=True)
-    p = p / p.norm(dim=-1).max(dim=1)[0].view(B, 1, 1)
+    return p / p.norm(dim=-1).max(dim=1)[0].view(-1, 1, 1)
+
+
+def synthetic_batch(B, N, seed, device, family="ball"):
+    """family "ball": uniform in the unit ball.  family "bridge": the shape the authors train on --
+    points on a deck plane, pier boxes and two cable/railing lines with strongly non-uniform density
+    (ball-query early exit and FPS pruning depend on it), 80 % distinct points padded to N by
+    repeating points like utils/simpdataset.py:143-149.  Colours U[0,1), labels 0..4."""
+    g = torch.Generator().manual_seed(seed)
+    if family == "ball":
+        v = torch.randn(B, N, 3, generator=g)
+        p = v / v.norm(dim=-1, keepdim=True) * torch.rand(B, N, 1, generator=g) ** (1.0 / 3.0)
+    elif family == "bridge":
+        M = int(N * 0.8)
+        u = torch.rand(B, M, 3, generator=g)
+        part = torch.rand(B, M, generator=g)
+        deck = torch.stack([u[..., 0] * 40 - 20, u[..., 1] * 6 - 3, u[..., 2] * 0.05], -1)            # 55 %: a 40 x 6 m slab
+        pier_x = (torch.randint(0, 4, (B, M), generator=g).float() - 1.5) * 10.0
+        pier = torch.stack([pier_x + u[..., 0] * 1.0, u[..., 1] * 4 - 2, -u[..., 2] * 8.0], -1)      # 25 %: four piers
+        rail_y = torch.where(u[..., 1] > 0.5, 3.0, -3.0)
+        rail = torch.stack([u[..., 0] * 40 - 20, rail_y + u[..., 1] * 0.02, 1.0 + u[..., 2] * 0.1], -1)  # 12 %: railings
+        ground = torch.stack([u[..., 0] * 50 - 25, u[..., 1] * 20 - 10, -8.0 - u[..., 2] * 0.5], -1)  # 8 %: ground patch
+        p = torch.where((part < 0.55).unsqueeze(-1), deck,
+                        torch.where((part < 0.80).unsqueeze(-1), pier, torch.where((part < 0.92).unsqueeze(-1), rail, ground)))
+        pad = torch.randint(0, M, (B, N - M), generator=g)                                            # simpdataset.py:146-148
+        p = torch.cat([p, torch.gather(p, 1, pad.unsqueeze(-1).expand(-1, -1, 3))], dim=1)
+        perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+        p = torch.gather(p, 1, perm.unsqueeze(-1).expand(-1, -1, 3))
+    else:
+        raise ValueError(family)
     colors = torch.rand(B, N, 3, generator=g)
     labels = torch.randint(0, 5, (B, N), generator=g)
-    return p.contiguous().to(device), colors.to(device), labels.to(device)
+    return _normalise(p).contiguous().to(device), colors.to(device), labels.to(device)
 
 
 def build_model(name, num_classes=5):
@@ -97,120 +128,123 @@ def cpu_baseline(model_name, N, budget_s=25.0):
                       f"({dt:.2f} s/step), oracle/torch_port.py (ATen port of the reference path)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="pn2_msg", choices=["pn2_msg", "pn2_ssg", "dgcnn", "bridgeseg"])
-    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default 16; dgcnn 8)")
-    ap.add_argument("--npoints", type=int, default=None, help="points per scene (default 16384; dgcnn 8192)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="do not overlap the next batch's FPS pyramid with the current backward pass")
-    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (fp32 mode)")
-    ap.add_argument("--mode", default="train", choices=["train", "infer"],
-                    help="train: fwd+loss+bwd+all-reduce+Adam (the headline metric); infer: eval-mode forward only, "
-                         "the reference's own published metric (eva_model.py:137-168, model_performance_comparison.csv)")
-    ap.add_argument("--graph", action="store_true",
-                    help="train mode: replay forward+backward as one captured hipGraph instead of launching every "
-                         "kernel from the host (measured equal on MI355X: the step is GPU-bound, so off by default; "
-                         "pn2_msg / pn2_ssg only)")
-    ap.add_argument("--loss", default="ce", choices=["ce", "bridge"],
-                    help="bridge: BridgeStructureLoss(alpha=80, rel_margin=0.3) of train_MulSca_BriStruNet_CB.py:151-156 "
-                         "(bridgeseg / pn2_msg / pn2_ssg logits [B,C,N])")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
-                    help="pointwise-MLP arithmetic: bf16 activations (BASELINE config 2) or the fp32 parity mode")
-    args = ap.parse_args()
+class Run:
+    """One timed configuration: model, data, optimiser, the step function, the timed loop."""
 
-    from pointcloud_bridge_amd import ops, parallel, rowmlp
-    rowmlp.set_precision(args.precision)
-    rank, world, local = parallel.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (HIP kernels, no CPU fallback)")
-    local = local % torch.cuda.device_count()  # ranks may share a GPU in a gloo rehearsal
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    RESIDENT_BATCHES = 4  # the loop walks over a few resident batches (step i prefetches the sampling of batch i+1)
 
-    B = args.batch or (8 if args.model == "dgcnn" else 16)
-    N = args.npoints or (8192 if args.model == "dgcnn" else 16384)
+    def __init__(self, args, model_name, precision, B, N, rank, world, device, mode="train", family="ball",
+                 graph=False, loss="ce", sync_bn=False, strong=False):
+        from pointcloud_bridge_amd import parallel, rowmlp
+        from pointcloud_bridge_amd.models import pointnet2_utils as pu
+        self.args, self.model_name, self.precision, self.mode, self.family = args, model_name, precision, mode, family
+        self.B, self.N, self.rank, self.world, self.device = B, N, rank, world, device
+        rowmlp.set_precision(precision)
+        torch.manual_seed(42)  # identical init on every rank; broadcast below makes it certain
+        model, self.cdim = build_model(model_name)
+        model = model.to(device).train()
+        if sync_bn and world > 1:
+            model = parallel.sync_batchnorm(model)
+        parallel.broadcast_parameters(model)
+        if args.no_dropout:  # equivalence runs: a sharded run cannot reproduce the single process's dropout masks
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+        self.model = model
+        self.use_graph = mode == "train" and graph
+        if self.use_graph and (model_name == "bridgeseg" or loss == "bridge"):
+            # The narrow encoder layers of BridgeSeg and BridgeStructureLoss still run ATen BatchNorm /
+            # reductions.  ATen's two-stage reductions (staging buffer + semaphores) return garbage on every
+            # replay of a captured hipGraph but the first on this stack (tools/graph_reduce_repro.py, a
+            # torch-only reproducer) -- a captured step must not contain one.
+            raise SystemExit("--graph: the BridgeSeg encoders / BridgeStructureLoss still contain ATen reductions, which "
+                             "do not survive hipGraph replay on this PyTorch-ROCm build (tools/graph_reduce_repro.py)")
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.params = params
+        # train_MulSca_PN2.py:125: Adam(lr=1e-3, weight_decay=1e-4) -- as one fused update over a flat
+        # parameter buffer (parallel.FlatAdam: torch's fused-Adam arithmetic, one launch instead of ~25)
+        self.opt = parallel.FlatAdam(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+        if self.use_graph:
+            self.bucket = parallel.FlatGradAllReduce(params, keep_grad_tensors=True, assign_views=False)
+        else:
+            self.bucket = parallel.OverlappedGradAllReduce.by_children(model)
+        # data: weak scaling = every rank its own batches; strong = one global batch, this rank's scenes
+        self.batches = []
+        for i in range(self.RESIDENT_BATCHES):
+            if strong:
+                x, c, lab = synthetic_batch(B * world, N, 1000 + 17 * i, "cpu", family)
+                sl = slice(rank * B, (rank + 1) * B)
+                self.batches.append(tuple(t[sl].contiguous().to(device) for t in (x, c, lab)))
+            else:
+                self.batches.append(synthetic_batch(B, N, 1000 + 17 * i + 1000 * rank, device, family))
+        pu.set_scene_shard(rank if strong else 0, world if strong else 1)
+        torch.manual_seed(7 + (0 if strong else rank))  # CPU generator: FPS start indices
+        self.prefetch = (not args.no_prefetch) and hasattr(model, "prefetch") and not self.use_graph
+        if loss == "bridge":
+            if self.cdim != 1:
+                raise SystemExit("--loss bridge expects [B,C,N] logits (bridgeseg, pn2_msg, pn2_ssg)")
+            from pointcloud_bridge_amd.losses import BridgeStructureLoss
+            crit = BridgeStructureLoss(alpha=80, rel_margin=0.3).to(device)  # train_MulSca_BriStruNet_CB.py:151-156
+            self.loss_of = lambda logits, batch: crit(logits.float(), batch[2], batch[0])
+        else:
+            self.loss_of = lambda logits, batch: loss_fn(logits, batch[2], self.cdim)
+        self.i = 0
+        if mode == "infer":
+            model.eval()
+        if self.use_graph:
+            self._capture()
 
-    torch.manual_seed(42)  # identical init on every rank; broadcast below makes it certain
-    model, cdim = build_model(args.model)
-    model = model.to(device).train()
-    if args.sync_bn and world > 1:
-        model = parallel.sync_batchnorm(model)
-    parallel.broadcast_parameters(model)
-    use_graph = args.mode == "train" and args.graph and args.precision == "bf16"
-    if use_graph and args.model in ("dgcnn", "bridgeseg"):
-        # replaying a captured DGCNN step ended in a GPU memory fault on MI355X (cause not found yet;
-        # the eager step is clean under the same tests) -- refuse rather than risk the device; the
-        # BridgeSeg step has not been captured yet
-        raise SystemExit("--graph is supported for pn2_msg / pn2_ssg only")
-    params = [p for p in model.parameters() if p.requires_grad]
-    bucket = parallel.FlatGradAllReduce(params, keep_grad_tensors=use_graph, assign_views=False)
-    # train_MulSca_PN2.py:125: Adam(lr=1e-3, weight_decay=1e-4) -- as one fused update over a flat
-    # parameter buffer (parallel.FlatAdam: torch's fused-Adam arithmetic, one launch instead of ~25)
-    opt = parallel.FlatAdam(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
-    xyz, colors, labels = synthetic_batch(B, N, 1000 + rank, device)
-    torch.manual_seed(7 + rank)  # CPU generator: FPS start indices
+    # -- steps ------------------------------------------------------------------------------------
+    def _batch(self, k=0):
+        return self.batches[(self.i + k) % len(self.batches)]
 
-    prefetch = (not args.no_prefetch) and hasattr(model, "prefetch")
-    if args.loss == "bridge":
-        if cdim != 1:
-            raise SystemExit("--loss bridge expects [B,C,N] logits (bridgeseg, pn2_msg, pn2_ssg)")
-        from pointcloud_bridge_amd.losses import BridgeStructureLoss
-        crit = BridgeStructureLoss(alpha=80, rel_margin=0.3).to(device)  # train_MulSca_BriStruNet_CB.py:151-156
-
-        def loss_of(logits):
-            return crit(logits.float(), labels, xyz)
-    else:
-        def loss_of(logits):
-            return loss_fn(logits, labels, cdim)
-
-    def train_step():
-        bucket.zero()
-        loss = loss_of(model(xyz, colors))
-        if prefetch:
-            model.prefetch(xyz)  # sampling pyramid of the next batch, concurrent with this backward
+    def train_step(self):
+        batch = self._batch()
+        self.bucket.zero()
+        loss = self.loss_of(self.model(batch[0], batch[1]), batch)
+        if self.prefetch:
+            self.model.prefetch(self._batch(1)[0])  # sampling pyramid of the NEXT batch, concurrent with this backward
         loss.backward()
-        bucket.reduce()
-        opt.step(bucket.flat)
+        flat = self.bucket.finish()
+        if self.args.dump and self.i == 0:
+            self.first_grad = flat.detach().clone()  # the averaged gradient of the first step (equivalence tests)
+        self.opt.step(flat)
+        self.i += 1
         return loss
 
-    def infer_step():
+    def infer_step(self):
+        batch = self._batch()
         with torch.no_grad():
-            if prefetch and hasattr(model, "set_next"):
-                model.set_next(xyz)  # pipelined serving: the next batch's FPS pyramid runs beside this pass's decoder
-            return loss_of(model(xyz, colors))
+            if self.prefetch and hasattr(self.model, "set_next"):
+                self.model.set_next(self._batch(1)[0])  # pipelined serving: the next batch's FPS runs beside this pass's decoder
+            loss = self.loss_of(self.model(batch[0], batch[1]), batch)
+        self.i += 1
+        return loss
 
-    if args.mode == "infer":
-        model.eval()
-    step = train_step if args.mode == "train" else infer_step
-
-    if use_graph:
-        # Forward + loss + backward (+ the next batch's sampling pyramid on a side stream) replayed
-        # as ONE hipGraph: ~700 kernel launches per step stop costing host time.  The CPU-generator
-        # draws for FPS stay on the host (StaticSampling.draw), the gradient all-reduce (RCCL) and the
-        # fused Adam step stay outside the graph.
+    def _capture(self):
+        """Forward + loss + backward (+ the next step's sampling pyramid on a forked stream) replayed as
+        ONE hipGraph.  The CPU-generator draws for FPS stay on the host (StaticSampling.draw), the
+        gradient all-reduce and the fused Adam step stay outside the graph.  One resident batch (the
+        graph's tensors are fixed)."""
         from pointcloud_bridge_amd.models import pointnet2_utils as pu
+        model, bucket, opt = self.model, self.bucket, self.opt
+        xyz, colors, _ = self.batches[0]
+        batch = self.batches[0]
         static = None
-        if hasattr(model, "prefetch"):
+        if hasattr(model, "sa1"):
             static = pu.StaticSampling(xyz, [model.sa1.npoint, model.sa2.npoint, model.sa3.npoint])
             pu.set_static_sampling(static)
             static.draw()
             static.compute(xyz)
         side = torch.cuda.Stream()
-        loss_buf = torch.zeros((), device=device)
+        loss_buf = torch.zeros((), device=self.device)
 
         def fwd_bwd():
-            loss = loss_of(model(xyz, colors))
+            loss = self.loss_of(model(xyz, colors), batch)
             if static is not None:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    static.compute(xyz)          # pyramid of the next batch, beside the backward pass
+                    static.compute(xyz)          # pyramid of the next step, beside the backward pass
             loss.backward()
             if static is not None:
                 torch.cuda.current_stream().wait_stream(side)
@@ -234,8 +268,7 @@ def main():
             static.draw()
         with torch.cuda.graph(graph):
             fwd_bwd()
-
-        grads = [p.grad for p in model.parameters() if p.grad is not None]  # the graph's fixed tensors
+        grads = [p.grad for p in self.params if p.grad is not None]  # the graph's fixed tensors
 
         def graph_step():
             if static is not None:
@@ -256,81 +289,197 @@ def main():
             opt.step(bucket.flat)
             return loss_buf
 
-        step = graph_step
+        self.graph_step, self.eager_step = graph_step, eager_step
 
-    def fence():
+    # -- the timed loop ---------------------------------------------------------------------------
+    def fence(self):
         torch.cuda.synchronize()
-        if world > 1:
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    # The interpreter's cyclic garbage collector stops the host for tens of milliseconds at a time
-    # (a step creates thousands of short-lived tensor objects); such a pause drains the GPU queue.
-    # As in production training loops it is run at chosen points instead: here, before and after
-    # the timed steps.
-    import gc
-    gc.collect()
-    gc.disable()
-    fence()
-    ops.kernel_timer_start()
-    t0 = time.perf_counter()
-    host_s = 0.0  # time the host spends enqueueing (diagnostic: host-bound vs GPU-bound)
-    for i in range(args.steps):
-        # HIP events around the roofline kernel on every 10th step (launched eagerly in graph mode)
-        sampled = i % 10 == 0 and not os.environ.get("PCB_BENCH_NO_ROOFLINE")
-        ops.kernel_timer_enable(sampled)
-        h0 = time.perf_counter()
-        loss = (eager_step if (use_graph and sampled) else step)()
-        host_s += time.perf_counter() - h0
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    launches, kernel_ms, units = ops.kernel_timer_stop()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(self, steps, warmup, roofline=True):
+        from pointcloud_bridge_amd import ops
+        step = (self.graph_step if self.use_graph else self.train_step) if self.mode == "train" else self.infer_step
+        losses = []
+        for _ in range(warmup):
+            step()
+        # The interpreter's cyclic garbage collector stops the host for tens of milliseconds at a time
+        # (a step creates thousands of short-lived tensor objects); such a pause drains the GPU queue.
+        # As in production training loops it is run at chosen points instead: here, before and after
+        # the timed steps.
+        gc.collect()
+        gc.disable()
+        self.fence()
+        ops.kernel_timer_start()
+        t0 = time.perf_counter()
+        host_s = 0.0  # time the host spends enqueueing (diagnostic: host-bound vs GPU-bound)
+        nsampled = 0
+        for i in range(steps):
+            # HIP events around the roofline kernel on every 10th step (launched eagerly in graph mode)
+            sampled = bool(roofline and i % 10 == 0 and not os.environ.get("PCB_BENCH_NO_ROOFLINE"))
+            nsampled += sampled
+            ops.kernel_timer_enable(sampled)
+            h0 = time.perf_counter()
+            loss = (self.eager_step if (self.use_graph and sampled) else step)()
+            host_s += time.perf_counter() - h0
+            if self.args.dump:
+                lg = loss.detach().clone()
+                if self.world > 1:  # the mean over ALL scenes, as a single process would report it
+                    dist.all_reduce(lg, op=dist.ReduceOp.SUM)
+                    lg /= self.world
+                losses.append(lg)
+        self.fence()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        launches, kernel_ms, nt_bytes = ops.kernel_timer_stop()
+        fps_n, fps_ms, _ = ops.kernel_timer_read(1)
+        all_n, _, all_bytes = ops.kernel_timer_read(-1)
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # (a graph replay launches nothing through the library's entry points: its bytes are those of the eager steps)
+        counted_steps = nsampled if self.use_graph else steps
+        res = {"ms_per_step": dt / steps * 1e3, "points_per_s": self.world * self.B * self.N / (dt / steps),
+               "loss": float(loss.detach()), "host_enqueue_ms_per_step": host_s / steps * 1e3,
+               "nt_launches": launches, "nt_ms": kernel_ms, "nt_bytes": nt_bytes,
+               "fps_ms_per_step": fps_ms / nsampled if (fps_n and nsampled) else None,
+               "lib_launches_per_step": all_n / max(counted_steps, 1),
+               "lib_bytes_per_step": all_bytes / max(counted_steps, 1)}
+        if self.args.dump:
+            res["losses"] = [float(x) for x in losses]
+        return res
+
+    def close(self):
+        from pointcloud_bridge_amd.models import pointnet2_utils as pu
+        pu.set_static_sampling(None)
+        pu.set_scene_shard(0, 1)
+        if hasattr(self.bucket, "close"):
+            self.bucket.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="pn2_msg", choices=["pn2_msg", "pn2_ssg", "dgcnn", "bridgeseg"])
+    ap.add_argument("--batch", type=int, default=None,
+                    help="scenes per GPU (default 16; dgcnn 8); with --scaling strong: scenes of the GLOBAL batch")
+    ap.add_argument("--npoints", type=int, default=None, help="points per scene (default 16384; dgcnn 8192)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: B scenes per GPU (the default); strong: ONE global batch of B scenes split over the "
+                         "ranks, FPS start indices drawn for the global batch on every rank (SURVEY 8e)")
+    ap.add_argument("--data", default="ball", choices=["ball", "bridge"],
+                    help="synthetic family: unit-ball clouds, or bridge-like clouds (deck / piers / railings, "
+                         "non-uniform density, 20 %% repeated points as the reference's padding produces)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other configurations")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not overlap the next batch's FPS pyramid with the current backward pass")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="SyncBatchNorm across ranks (both precisions: statistics all-reduced inside the fused engine)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train: fwd+loss+bwd+all-reduce+Adam (the headline metric); infer: eval-mode forward only, "
+                         "the reference's own published metric (eva_model.py:137-168, model_performance_comparison.csv)")
+    ap.add_argument("--graph", action="store_true",
+                    help="train mode: replay forward+backward as one captured hipGraph instead of launching every "
+                         "kernel from the host (pn2_msg / pn2_ssg / dgcnn)")
+    ap.add_argument("--loss", default="ce", choices=["ce", "bridge"],
+                    help="bridge: BridgeStructureLoss(alpha=80, rel_margin=0.3) of train_MulSca_BriStruNet_CB.py:151-156 "
+                         "(bridgeseg / pn2_msg / pn2_ssg logits [B,C,N])")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="row type of the fused MLP engine: bf16 activations (BASELINE config 2) or fp32 rows (parity mode)")
+    ap.add_argument("--dump", default=None, help="rank 0 writes step losses and the final parameters to this .pt file")
+    ap.add_argument("--no-dropout", action="store_true", help="Dropout layers with p = 0 (sharded-vs-single equivalence runs)")
+    args = ap.parse_args()
+
+    from pointcloud_bridge_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP kernels, no CPU fallback)")
+    local = local % torch.cuda.device_count()  # ranks may share a GPU in a gloo rehearsal
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    B = args.batch or (8 if args.model == "dgcnn" else 16)
+    N = args.npoints or (8192 if args.model == "dgcnn" else 16384)
+    strong = args.scaling == "strong"
+    if strong:
+        if B % world:
+            raise SystemExit(f"--scaling strong: the global batch of {B} scenes does not split over {world} ranks")
+        B //= world
+
+    run = Run(args, args.model, args.precision, B, N, rank, world, device, args.mode, args.data, args.graph, args.loss,
+              args.sync_bn, strong)
+    res = run.timed(args.steps, args.warmup)
+    if args.dump and rank == 0:
+        torch.save({"losses": res["losses"], "flat": run.opt.flat.detach().cpu(),
+                    "first_grad": getattr(run, "first_grad", torch.zeros(0)).cpu()}, args.dump)
+    prefetching = run.prefetch
+    run.close()
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
         # BASELINE.md publishes one number on this path that a bench mode reproduces exactly:
         # PointNet2 (SSG) inference, B=4 x N=4096, fp32, eval, 1 GPU (RTX 4090): 35 557 pts/s
         # (Highway_bridge/model_performance_comparison.csv:4).  The headline fwd+bwd metric has none.
         vs_baseline = None
         if (args.mode == "infer" and args.model == "pn2_ssg" and B == 4 and N == 4096
                 and args.precision == "fp32" and world == 1):
-            vs_baseline = (B * N / (dt / args.steps)) / 35557.0
+            vs_baseline = res["points_per_s"] / 35557.0
         traffic = None  # HBM bytes per launch from the committed PMC passes of this same workload
-        pmc = os.path.join(REPO, "profiles", "r01_pmc_gemm_nt_bf16.json")
-        if (args.model == "pn2_msg" and args.precision == "bf16" and B == 16 and N == 16384
-                and os.path.exists(pmc)):
-            with open(pmc) as f:
-                traffic = json.load(f)["traffic_bytes_per_launch"]
-        alg_bytes = units * ROOFLINE_BYTES_PER_UNIT / max(launches, 1)  # per launch
-        avg_s = kernel_ms / max(launches, 1) * 1e-3
+        for pmc_name in ("r02_pmc_gemm_nt_bf16.json", "r01_pmc_gemm_nt_bf16.json"):
+            pmc = os.path.join(REPO, "profiles", pmc_name)
+            if (args.model == "pn2_msg" and args.precision == "bf16" and B == 16 and N == 16384 and args.data == "ball"
+                    and args.mode == "train" and os.path.exists(pmc)):
+                with open(pmc) as f:
+                    traffic = json.load(f)["traffic_bytes_per_launch"]
+                break
+        launches = res["nt_launches"]
+        alg_bytes = res["nt_bytes"] / max(launches, 1)   # per launch
+        avg_s = res["nt_ms"] / max(launches, 1) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if launches else 0.0
+        step_s = res["ms_per_step"] * 1e-3
+        whole = res["lib_bytes_per_step"] / step_s / 1e9
+        workload = (f"{args.model} "
+                    + (("fwd+" + ("CE" if args.loss == "ce" else "BridgeStructureLoss") + "+bwd+overlapped flat grad-allreduce+Adam")
+                       if args.mode == "train" else
+                       ("eval-mode forward+CE" + (", next batch FPS pipelined" if prefetching else "")))
+                    + f", B={B} scenes/GPU x N={N} pts, "
+                    + ("unit-ball clouds" if args.data == "ball" else "bridge-like clouds (deck/piers/railings, 20% repeated points)")
+                    + f", {Run.RESIDENT_BATCHES} resident batches in rotation (configs[1] of BASELINE.json)")
         out = {
             "metric": (("points/sec fwd+bwd, " if args.mode == "train" else "points/sec inference (eval forward), ")
                        + {"dgcnn": f"DGCNN k=20 EdgeConv seg N={N} B={B}",
                           "bridgeseg": f"BridgeSeg (EnhancedPointNet2: bridge encoders + PointNet++ MSG) N={N} B={B}"}
-                       .get(args.model, f"PointNet++ seg N={N} B={B}")),
-            "value": world * B * N / (dt / args.steps),
+                       .get(args.model, f"PointNet++ seg N={N} B={B * world if strong else B}")),
+            "value": res["points_per_s"],
             "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": vs_baseline, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} {('fwd+' + ('CE' if args.loss == 'ce' else 'BridgeStructureLoss') + '+bwd+grad-allreduce+Adam') if args.mode == 'train' else ('eval-mode forward+CE' + (', next batch FPS pipelined' if (prefetch and hasattr(model, 'set_next')) else ''))}, B={B} scenes/GPU x N={N} pts, "
-                                   f"unit-ball clouds (configs[1] of BASELINE.json)",
-                       "scenes_per_gpu": B, "points_per_scene": N, "parallelism": f"dp{world} (scenes sharded)",
-                       "loss": float(loss.detach()),
-                       "host_enqueue_ms_per_step": host_s / args.steps * 1e3},
+            "config": {"workload": workload, "scenes_per_gpu": B, "points_per_scene": N,
+                       "parallelism": f"dp{world} (scenes sharded, {args.scaling} scaling"
+                                      + (", SyncBatchNorm" if args.sync_bn and world > 1 else "") + ")",
+                       "loss": res["loss"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+                       "library_launches_per_step": res["lib_launches_per_step"], "graph": bool(args.graph)},
             "roofline": {"bound": "hbm", "kernel": ROOFLINE_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": launches, "avg_launch_us": avg_s * 1e6,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         # algorithmic bytes of ALL kernel families of the library over the step time
+                         # (ATen glue not counted), with the sampling chain's time as a separate latency term
+                         "whole_step": {"algorithmic_bytes_per_step": res["lib_bytes_per_step"], "achieved": whole,
+                                        "frac": whole / HBM_PEAK_GBS, "unit": "GB/s",
+                                        "fps_ms_per_step": res["fps_ms_per_step"],
+                                        "fps_note": "FPS pyramid of the next batch: a latency chain on a side stream "
+                                                    "(1 workgroup per scene), concurrent with the backward pass"}},
         }
+        if world == 1 and not args.no_extras and args.model == "pn2_msg" and args.mode == "train" and not args.dump:
+            out["extra"] = extras(args, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, N)
         print(json.dumps(out), flush=True)
@@ -339,12 +488,50 @@ def main():
         dist.destroy_process_group()
 
 
-# Dominant kernel of the step (profiles/): the fused bf16 row GEMM pcb_gemm_nt_bf16 (forward and
+def extras(args, device):
+    """Short runs (a few steps each) of the other configurations SURVEY section 8(d) names, so that the
+    driver's one bench line carries them: cfg3 DGCNN, cfg4's network BridgeSeg, the fp32 parity mode
+    of the headline network, the headline network on bridge-like clouds, and the captured-graph step."""
+    out = {}
+    plan = [
+        ("pn2_msg_bridge_like_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, family="bridge")),
+        ("pn2_msg_graph_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, graph=True)),
+        ("pn2_msg_fp32_B16_N16384", dict(model_name="pn2_msg", precision="fp32", B=16, N=16384)),
+        ("dgcnn_k20_B8_N8192_bf16", dict(model_name="dgcnn", precision="bf16", B=8, N=8192)),
+        ("bridgeseg_B16_N16384_bf16", dict(model_name="bridgeseg", precision="bf16", B=16, N=16384)),
+        ("pn2_msg_infer_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, mode="infer")),
+    ]
+    for name, kw in plan:
+        try:
+            torch.cuda.empty_cache()
+            run = Run(args, rank=0, world=1, device=device, **kw)
+            res = run.timed(8, 4)
+            run.close()
+            launches = res["nt_launches"]
+            entry = {"ms_per_step": res["ms_per_step"], "points_per_s": res["points_per_s"], "loss": res["loss"],
+                     "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+                     "library_launches_per_step": res["lib_launches_per_step"],
+                     "whole_step_GBps": res["lib_bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 1e9,
+                     "fps_ms_per_step": res["fps_ms_per_step"]}
+            if launches:
+                entry["gemm_nt_GBps"] = res["nt_bytes"] / (res["nt_ms"] * 1e-3) / 1e9
+                entry["gemm_nt_avg_us"] = res["nt_ms"] / launches * 1e3
+            out[name] = entry
+            del run
+        except BaseException as e:  # an extra must never cost the headline line
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    from pointcloud_bridge_amd import rowmlp
+    rowmlp.set_precision(args.precision)
+    return out
+
+
+# Dominant kernel of the step (profiles/): the fused row GEMM pcb_gemm_nt_* (forward and
 # input-gradient GEMMs of every pointwise layer).  It is HBM-bound (skinny: K, N <= a few hundred).
 # Work unit = one algorithmic HBM byte: every activation operand read once and the output written
-# once, 2 B per bf16 element; the wrappers pass that count per launch.
+# once (DESIGN.md section 5); the library counts them per launch.
 ROOFLINE_KERNEL = "pcb_gemm_nt_bf16"
-ROOFLINE_BYTES_PER_UNIT = 1.0
 
 if __name__ == "__main__":
     main()

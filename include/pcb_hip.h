@@ -665,15 +665,22 @@ int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *
                         const float *ctr, float *du, float *dv, float *dwx, void *stream);
 
 /*
- * HIP-event timing of the gemm_nt kernel family (pcb_gemm_nt_bf16 / pcb_gemm_nt_red_bf16, also when
- * issued by the stack calls) on the stream they are launched on -- bench.py's roofline figure.
- * pcb_timer_start arms and clears; pcb_timer_enable(0/1) pauses/resumes sampling; pcb_timer_stop
- * synchronises the recorded events and returns launches, their summed duration and their
- * algorithmic HBM bytes (A operand as read by its prologue + bf16 output [+ y for the RED variant]).
+ * Instruments of bench.py (off unless armed; the only other process-wide state besides the hint):
+ *  - HIP-event timing, on the stream they are launched on, of two kernel categories:
+ *      0  the gemm_nt family (pcb_gemm_nt_* / pcb_gemm_nt_red_* / _bias / _f32out, also when issued
+ *         by the stack calls) -- the roofline kernel;   1  pcb_fps -- the step's latency chain.
+ *  - a byte counter: every entry point adds the ALGORITHMIC HBM bytes of the launch it enqueued
+ *    (operands read once + outputs written once; for gemm_nt: A operand as read by its prologue +
+ *    output [+ y for the RED variant]) -- the whole-step traffic figure.
+ * pcb_timer_start arms and clears both; pcb_timer_enable(0/1) pauses/resumes the EVENT sampling (the
+ * byte counter keeps counting); pcb_timer_stop disarms, synchronises the recorded events and returns
+ * category 0: launches, their summed duration, their bytes.  pcb_timer_read(category, ...) afterwards:
+ * the same for category 0 or 1; category -1: every accounted launch and its bytes (duration 0).
  */
 int pcb_timer_start(void);
 int pcb_timer_enable(int on);
 int pcb_timer_stop(long *launches, double *milliseconds, double *bytes);
+int pcb_timer_read(int category, long *launches, double *milliseconds, double *bytes);
 
 #ifdef __cplusplus
 }

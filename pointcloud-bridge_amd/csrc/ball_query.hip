@@ -112,6 +112,7 @@ extern "C" int pcb_ball_query(const float *xyz, const float *new_xyz, int B, int
     const dim3 grid((S + kCPW * kWaves - 1) / (kCPW * kWaves), B);
     hipLaunchKernelGGL((ball_query_kernel<1>), grid, dim3(kWaves * PCB_WAVE), 0, (hipStream_t)stream,
                        xyz, new_xyz, N, S, r2, nsample, out_idx, 0.0f, 0, (int64_t *)nullptr);
+    pcb_account(12.0 * ((double)N + S) * B + 8.0 * (double)S * nsample * B);
     return pcb_check_launch();
 }
 
@@ -124,6 +125,7 @@ extern "C" int pcb_ball_query2(const float *xyz, const float *new_xyz, int B, in
     const dim3 grid((S + kCPW * kWaves - 1) / (kCPW * kWaves), B);
     hipLaunchKernelGGL((ball_query_kernel<2>), grid, dim3(kWaves * PCB_WAVE), 0, (hipStream_t)stream,
                        xyz, new_xyz, N, S, r2_a, nsample_a, out_idx_a, r2_b, nsample_b, out_idx_b);
+    pcb_account(12.0 * ((double)N + S) * B + 8.0 * (double)S * (nsample_a + nsample_b) * B);
     return pcb_check_launch();
 }
 
@@ -157,5 +159,6 @@ extern "C" int pcb_square_distance(const float *src, const float *dst, int B, in
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(square_distance_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        src, dst, N, M, out, total);
+    pcb_account(12.0 * ((double)N + M) * B + 4.0 * (double)N * M * B);
     return pcb_check_launch();
 }

@@ -422,6 +422,14 @@ extern "C" int pcb_fps(const float *xyz, int B, int N, int S, const int64_t *sta
 {
     if (!xyz || !start_idx || !out_idx || B <= 0 || N <= 0 || S <= 0) return PCB_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
+    // bench.py: the sampling chain is the step's latency term, timed as its own category (1)
+    struct Timed {
+        hipStream_t st;
+        hipEvent_t ev;
+        double bytes;
+        ~Timed() { pcb_timer_end(st, ev, bytes, 30, 0, 0, 0); }
+    } timed{st, nullptr, 12.0 * (double)N * B + 16.0 * (double)S * B};
+    pcb_timer_begin_cat(st, &timed.ev, 1);
     // Few waves for small clouds (cheaper cross-wave step), all 16 waves of a CU for large ones.
     if (N <= 64) launch_regs<64, 1>(xyz, B, N, S, start_idx, out_idx, st);
     else if (N <= 128) launch_regs<64, 2>(xyz, B, N, S, start_idx, out_idx, st);

@@ -155,6 +155,7 @@ extern "C" int pcb_gather_rows(const float *points, const int64_t *idx, int B, i
     const size_t total = (size_t)B * M * C;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        points, idx, N, C, M, out, total);
+    pcb_account(8.0 * (double)B * M * C + 8.0 * B * M);
     return pcb_check_launch();
 }
 
@@ -165,6 +166,7 @@ extern "C" int pcb_gather_rows_bwd(const float *grad_out, const int64_t *idx, in
     const size_t total = (size_t)B * M * C;
     hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(grid_for(total)), dim3(256), 0,
                        (hipStream_t)stream, grad_out, idx, N, C, M, grad_points, total);
+    pcb_account(8.0 * (double)B * M * C + 8.0 * B * M);
     return pcb_check_launch();
 }
 
@@ -177,6 +179,7 @@ extern "C" int pcb_group_points(const float *xyz, const float *new_xyz, const fl
     const size_t total = (size_t)B * S * ns * (3 + C);
     hipLaunchKernelGGL(group_points_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        xyz, new_xyz, feat, idx, N, S, ns, C, out, total);
+    pcb_account(8.0 * (double)B * S * ns * (3 + C) + 8.0 * B * S * ns);
     return pcb_check_launch();
 }
 
@@ -187,6 +190,7 @@ extern "C" int pcb_group_points_bwd(const float *grad_out, const int64_t *idx, i
     const size_t total = (size_t)B * S * ns * C;
     hipLaunchKernelGGL(group_points_bwd_kernel, dim3(grid_for(total)), dim3(256), 0,
                        (hipStream_t)stream, grad_out, idx, N, S, ns, C, grad_feat, total);
+    pcb_account(8.0 * (double)B * S * ns * C + 8.0 * B * S * ns);
     return pcb_check_launch();
 }
 
@@ -197,6 +201,7 @@ extern "C" int pcb_edge_features(const float *x, const int64_t *idx, int B, int 
     const size_t total = (size_t)B * N * k * 2 * D;
     hipLaunchKernelGGL(edge_features_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        x, idx, N, D, k, out, total);
+    pcb_account(4.0 * (double)B * N * D + 8.0 * (double)B * N * k + 8.0 * (double)B * N * k * D);
     return pcb_check_launch();
 }
 
@@ -207,5 +212,6 @@ extern "C" int pcb_edge_features_bwd(const float *grad_out, const int64_t *idx, 
     const size_t total = (size_t)B * N * D;
     hipLaunchKernelGGL(edge_features_bwd_kernel, dim3(grid_for(total)), dim3(256), 0,
                        (hipStream_t)stream, grad_out, idx, N, D, k, grad_x, total);
+    pcb_account(12.0 * (double)B * N * k * D + 8.0 * (double)B * N * k);
     return pcb_check_launch();
 }

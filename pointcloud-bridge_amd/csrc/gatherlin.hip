@@ -241,6 +241,7 @@ extern "C" int pcb_gather_add_bf16(const float *u, const float *v, const int64_t
     const long R = (long)B * S * ns;
     hipLaunchKernelGGL(gather_add_kernel, dim3((unsigned)nparts), dim3(kThreads), 0,
                        (hipStream_t)stream, u, v, idx, N, S, ns, C, R, (u16 *)y, sums, xyz, ctr, wx, ldw);
+    pcb_account(6.0 * R * C + 8.0 * R + (v ? 4.0 * B * S * C : 0.0));
     return pcb_check_launch();
 }
 
@@ -272,5 +273,6 @@ extern "C" int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, co
                            (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv, xyz, ctr, dwx);
     if (dwx)
         hipLaunchKernelGGL(sum_slabs_kernel, dim3((3 * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, dwx, 3 * C);
+    pcb_account(6.0 * (double)G * ns * C + (pooled ? 5.0 * G * C : 2.0 * (double)G * ns * C) + 8.0 * G * ns);
     return pcb_check_launch();
 }

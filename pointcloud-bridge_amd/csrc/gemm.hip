@@ -863,6 +863,7 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
         launch_tn<PRO_DY>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
     else
         launch_tn<PRO_DY_POOL>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
+    pcb_account((apro == PRO_DY ? 4.0 : 2.0) * R * M + (apro == PRO_DY_POOL ? 5.0 * (double)(R / (ns > 0 ? ns : 1)) * M : 0.0) + 2.0 * R * N);
     return pcb_check_launch();
 }
 

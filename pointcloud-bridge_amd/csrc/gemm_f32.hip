@@ -452,15 +452,28 @@ OperandF make_operand(const void *a0, const void *a1, long ld, const float *scal
     return o;
 }
 
+// Algorithmic HBM bytes of one gemm_nt launch (fp32 rows): the A operand as its prologue reads it + the
+// output (+ the y rows of the RED epilogue); weights and per-channel vectors not counted.
+inline double nt_bytes(int pro, long R, int N, int K, int ns, bool with_red)
+{
+    double a = 4.0 * R * K;
+    if (pro == PRO_DY) a = 8.0 * R * K;
+    if (pro == PRO_DY_POOL) a = 4.0 * R * K + 5.0 * (double)(R / (ns > 0 ? ns : 1)) * K;
+    return a + 4.0 * R * N * (with_red ? 2.0 : 1.0);
+}
+
 int nt_dispatch(int pro, const OperandF &A, const float *w, long R, int N, int K, float *out, float *sums, int nparts,
                 hipStream_t st, const RedArgsF &red, bool with_red)
 {
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
     switch (pro) {
         case PRO_PLAIN: launch_nt<PRO_PLAIN>(A, w, R, N, K, out, sums, nparts, st, red, with_red); break;
         case PRO_BNACT: launch_nt<PRO_BNACT>(A, w, R, N, K, out, sums, nparts, st, red, with_red); break;
         case PRO_DY: launch_nt<PRO_DY>(A, w, R, N, K, out, sums, nparts, st, red, with_red); break;
         default: launch_nt<PRO_DY_POOL>(A, w, R, N, K, out, sums, nparts, st, red, with_red); break;
     }
+    pcb_timer_end(st, timed, nt_bytes(pro, R, N, K, A.ns, with_red), pro + (with_red ? 10 : 0), R, N, K);
     return pcb_check_launch();
 }
 
@@ -536,5 +549,6 @@ extern "C" int pcb_gemm_tn_f32(int apro, const void *dz, const void *y, const fl
         launch_tn<PRO_DY>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
     else
         launch_tn<PRO_DY_POOL>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
+    pcb_account((apro == PRO_DY ? 8.0 : 4.0) * R * M + (apro == PRO_DY_POOL ? 5.0 * (double)(R / (ns > 0 ? ns : 1)) * M : 0.0) + 4.0 * R * N);
     return pcb_check_launch();
 }

@@ -262,7 +262,41 @@ int prep_linear_bias(const float *w, const float *bias, int n, int k, int npad, 
     return pcb_check_launch();
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t *__restrict__ p, size_t words)
+{
+    const size_t vec = words >> 2;
+    uint4 *__restrict__ v = reinterpret_cast<uint4 *>(p);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < vec; i += (size_t)gridDim.x * 256) v[i] = make_uint4(0, 0, 0, 0);
+    for (size_t i = (vec << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void copy_kernel(uint32_t *__restrict__ d, const uint32_t *__restrict__ s, size_t words)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+
 }  // namespace
+
+int pcb_zero_async(void *ptr, size_t bytes, hipStream_t st)
+{
+    if (!ptr || (bytes & 3) || ((uintptr_t)ptr & 15)) return PCB_ERR_INVALID_ARG;
+    if (!bytes) return PCB_OK;
+    const size_t words = bytes >> 2;
+    size_t blocks = ((words >> 2) + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)ptr, words);
+    return pcb_check_launch();
+}
+
+int pcb_copy_async(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    if (!dst || !src || (bytes & 3)) return PCB_ERR_INVALID_ARG;
+    if (!bytes) return PCB_OK;
+    const size_t words = bytes >> 2;
+    size_t blocks = (words + 255) / 256;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)dst, (const uint32_t *)src, words);
+    return pcb_check_launch();
+}
 
 int pcb_busy_cus() { return g_shared_cus.load(std::memory_order_relaxed); }
 

@@ -267,6 +267,7 @@ int launch_knn(const float *x, float *norms, int B, int N, int D, int k, int64_t
         hipLaunchKernelGGL((knn_mfma_kernel<DP, 20>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out, only_if, stride);
     else
         hipLaunchKernelGGL((knn_mfma_kernel<DP, 32>), grid, dim3(kThreads), 0, st, x, norms, N, D, k, out, only_if, stride);
+    if (!only_if) pcb_account(4.0 * (double)D * N * B + 8.0 * (double)N * k * B);  // (the flagged form rides on pcb_knn_xyz's count)
     return pcb_check_launch();
 }
 

@@ -341,6 +341,7 @@ extern "C" int pcb_knn_xyz(const float *xyz, int B, int N, int k, float *norms, 
         hipLaunchKernelGGL(knn_grid_query_kernel<32>, grid, dim3(kQueryThreads), 0, st, sorted, oidx, cell_start, params, N,
                            k, out_idx);
     if (pcb_check_launch() != PCB_OK) return PCB_ERR_LAUNCH;
+    pcb_account(12.0 * (double)N * B + 8.0 * (double)N * k * B);
     // crowded scenes (flag set by the build kernel): all pairs
     return pcb_knn_flagged(xyz, B, N, 3, k, norms, out_idx, &params[0].crowded, (int)(sizeof(GridParams) / sizeof(int)), st);
 }

@@ -83,12 +83,23 @@ __device__ __forceinline__ int clamp_index(int64_t j, int n)
 }
 
 // roofline timer hooks (stack.hip): no-ops unless pcb_timer_start armed the timer
-void pcb_timer_begin(hipStream_t st, hipEvent_t *stop);
-void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes, int pro, long R, int N, int K);
+void pcb_timer_begin(hipStream_t st, hipEvent_t *stop);                 // category 0: the gemm_nt family
+void pcb_timer_begin_cat(hipStream_t st, hipEvent_t *stop, int cat);    // 1: farthest point sampling
+void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes, int pro, long R, int N, int K);  // also accounts `bytes`
+// algorithmic HBM bytes of a launch that is not event-timed (the whole-step figure of bench.py)
+void pcb_account(double bytes);
 
 // weight-gradient slab reductions of a whole stack in one launch (gemm.hip)
 void pcb_defer_reduces_begin();
 int pcb_defer_reduces_flush(hipStream_t st);
+
+// Zero-fill / device copy as KERNELS (gemm_shared.hip), never hipMemsetAsync / hipMemcpyAsync: a step
+// of this library must stay correct when it is captured into a hipGraph and replayed, and memset nodes
+// do not survive replay on this stack (captured steps that contained one -- this library's or ATen's
+// semaphore memset inside its two-stage reductions -- returned garbage on every replay but the first
+// once anything ran between replays; tools/graph_reduce_repro.py).  bytes must be a multiple of 4.
+int pcb_zero_async(void *ptr, size_t bytes, hipStream_t st);
+int pcb_copy_async(void *dst, const void *src, size_t bytes, hipStream_t st);
 
 static inline int pcb_check_launch()
 {

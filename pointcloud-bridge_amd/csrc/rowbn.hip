@@ -503,6 +503,7 @@ int colstats(const void *y, long rows, int C, float *sums, void *stream)
     const int RT = kThreads / (Cblk / E);
     hipLaunchKernelGGL(colstats_kernel<T>, dim3(grid_for(rows, RT * 8, 2048), nblk), dim3(kThreads), 0,
                        (hipStream_t)stream, (const uint4 *)y, rows, Cblk, C, sums);
+    pcb_account((double)sizeof(T) * rows * C);
     return pcb_check_launch();
 }
 
@@ -514,6 +515,7 @@ int bn_act(const void *y, const float *scale, const float *shift, long rows, int
     const long nvec = rows * (C / RowVec<T>::E);
     hipLaunchKernelGGL(bn_act_kernel<T>, dim3(grid_for(nvec)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4 *)y, scale, shift, C, slope_of(act), (uint4 *)z, nvec);
+    pcb_account(2.0 * sizeof(T) * rows * C);
     return pcb_check_launch();
 }
 
@@ -527,6 +529,7 @@ int bn_act_max(const void *y, const float *scale, const float *shift, long group
     hipLaunchKernelGGL(bn_act_max_kernel<T>, dim3(grid_for(nvec, kThreads, 8192)), dim3(kThreads), 0,
                        (hipStream_t)stream, (const uint4 *)y, scale, shift, C, ns, slope_of(act), (uint4 *)out,
                        argmax, nvec);
+    pcb_account((double)sizeof(T) * groups * ns * C + (sizeof(T) + 1.0) * groups * C);
     return pcb_check_launch();
 }
 
@@ -540,6 +543,7 @@ int bn_act_bwd_reduce(const void *dz, const void *y, const float *scale, const f
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(grid_for(rows, RT * 8, 2048)), dim3(kThreads), 0,
                        (hipStream_t)stream, (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd,
                        rows, C, slope_of(act), sums, 0);
+    pcb_account(2.0 * sizeof(T) * rows * C);
     return pcb_check_launch();
 }
 
@@ -556,6 +560,7 @@ int bn_act_max_bwd_reduce(const float *dout, const unsigned char *argmax, const 
     hipLaunchKernelGGL(bn_max_bwd_reduce_kernel<T>, dim3(grid_for(groups, RT * 4, 2048)), dim3(kThreads), 0,
                        (hipStream_t)stream, dout, argmax, (const T *)y, scale, shift, mean, invstd, groups,
                        C, ns, slope_of(act), sums, 0);
+    pcb_account((5.0 + sizeof(T)) * groups * C);
     return pcb_check_launch();
 }
 
@@ -571,6 +576,7 @@ int bn_act_bwd(const void *dz, const void *y, const float *scale, const float *s
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(nvec)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd, sums, rows, C, slope_of(act),
                        use_batch_stats, (uint4 *)dy, nvec);
+    pcb_account(3.0 * sizeof(T) * rows * C);
     return pcb_check_launch();
 }
 
@@ -587,6 +593,7 @@ int bn_act_max_bwd(const float *dout, const unsigned char *argmax, const void *y
     hipLaunchKernelGGL(bn_max_bwd_apply_kernel<T>, dim3(grid_for(nvec)), dim3(kThreads), 0, (hipStream_t)stream, dout,
                        argmax, (const uint4 *)y, scale, shift, mean, invstd, sums, rows, C, ns, slope_of(act),
                        use_batch_stats, (uint4 *)dy, nvec);
+    pcb_account(2.0 * sizeof(T) * rows * C + 5.0 * groups * C);
     return pcb_check_launch();
 }
 
@@ -600,6 +607,7 @@ int group_rows(const float *xyz, const float *new_xyz, const void *feat, const i
     const long nchunk = (long)B * S * ns * (Kp / E);
     hipLaunchKernelGGL(group_rows_kernel<T>, dim3(grid_for(nchunk, kThreads, 8192)), dim3(kThreads), 0,
                        (hipStream_t)stream, xyz, new_xyz, (const T *)feat, idx, N, S, ns, C, Kp, (T *)out, nchunk);
+    pcb_account(2.0 * sizeof(T) * (double)B * S * ns * Kp + 8.0 * B * S * ns);
     return pcb_check_launch();
 }
 
@@ -611,6 +619,7 @@ int group_rows_bwd(const void *grad_rows, const int64_t *idx, int B, int N, int 
     const long total = (long)B * S * ns * C;
     hipLaunchKernelGGL(group_rows_bwd_kernel<T>, dim3(grid_for(total, kThreads, 8192)), dim3(kThreads), 0,
                        (hipStream_t)stream, (const T *)grad_rows, idx, N, S, ns, C, Kp, grad_feat, total);
+    pcb_account((sizeof(T) + 4.0) * (double)B * S * ns * C + 8.0 * B * S * ns);
     return pcb_check_launch();
 }
 
@@ -622,6 +631,7 @@ int gate(const void *x, const void *a, void *out, long n, void *stream)
     const long nvec = n / E;
     hipLaunchKernelGGL(gate_kernel<T>, dim3(grid_for(nvec, kThreads, 8192)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4 *)x, (const uint4 *)a, (uint4 *)out, nvec);
+    pcb_account(3.0 * sizeof(T) * n);
     return pcb_check_launch();
 }
 
@@ -633,6 +643,7 @@ int gate_bwd(const void *g, const void *x, const void *a, void *dx, void *da, lo
     const long nvec = n / E;
     hipLaunchKernelGGL(gate_bwd_kernel<T>, dim3(grid_for(nvec, kThreads, 8192)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4 *)g, (const uint4 *)x, (const uint4 *)a, (uint4 *)dx, (uint4 *)da, nvec);
+    pcb_account(5.0 * sizeof(T) * n);
     return pcb_check_launch();
 }
 

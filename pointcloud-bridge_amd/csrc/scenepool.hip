@@ -196,6 +196,7 @@ int scene_concat(const void *a, const void *g, int B, int N, int C1, int C2, voi
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(scene_concat_kernel<T>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4 *)a, (const uint4 *)g, N, C1, C2, (uint4 *)out, nvec);
+    pcb_account(2.0 * sizeof(T) * (double)B * N * (C1 + C2));
     return pcb_check_launch();
 }
 
@@ -214,6 +215,7 @@ int scene_colsum(const void *d, int B, int N, int ld, int col0, int C, void *out
     const long total = (long)B * C;
     hipLaunchKernelGGL(scene_colsum_final_kernel<T>, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                        workspace, splits, total, (T *)out);
+    pcb_account((double)sizeof(T) * B * N * C);
     return pcb_check_launch();
 }
 
@@ -225,7 +227,7 @@ int scene_max(const void *rows, int B, int N, int C, void *out, int *arg, void *
     if (C % E) return PCB_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *keys = (unsigned long long *)workspace;
-    if (hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)B * C, st) != hipSuccess) return PCB_ERR_LAUNCH;
+    if (pcb_zero_async(keys, sizeof(unsigned long long) * (size_t)B * C, st) != PCB_OK) return PCB_ERR_LAUNCH;
     const int CT = C / E;
     const int CTb = CT < 32 ? CT : 32;                    // column chunks per block
     const int RT = kThreads / CTb;
@@ -238,6 +240,7 @@ int scene_max(const void *rows, int B, int N, int C, void *out, int *arg, void *
     const long total = (long)B * C;
     hipLaunchKernelGGL(scene_max_decode_kernel<T>, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
                        keys, total, (T *)out, arg);
+    pcb_account((double)sizeof(T) * B * N * C);
     return pcb_check_launch();
 }
 
@@ -252,6 +255,7 @@ int scene_max_bwd(const void *g, const int *arg, int B, int N, int C, void *dz, 
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(scene_max_bwd_kernel<T>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, (const T *)g,
                        arg, N, C, (uint4 *)dz, nvec);
+    pcb_account((double)sizeof(T) * B * N * C);
     return pcb_check_launch();
 }
 

@@ -23,17 +23,27 @@
 #include "gemm_shared.h"
 
 // ---- roofline timer -------------------------------------------------------------------------
+// Two instruments for bench.py, both off unless pcb_timer_start armed them:
+//   * HIP events around the launches of two kernel categories -- 0: the gemm_nt family (the roofline
+//     kernel), 1: farthest point sampling (the step's latency chain) -- on the stream they run on;
+//   * a byte counter: every entry point adds the ALGORITHMIC HBM bytes of its launch (operands read
+//     once + outputs written once), the whole-step figure of the bench line.
 namespace {
+constexpr int kCats = 2;
 struct Timer {
     std::mutex mu;
     bool armed = false;    // between pcb_timer_start and pcb_timer_stop
-    bool on = false;       // sampling enabled right now
-    struct Ev { hipEvent_t first, second, third; };  // start | stop | a second stop right behind it
+    bool on = false;       // event sampling enabled right now
+    struct Ev { hipEvent_t first, second, third; int cat; double bytes; };  // start | stop | a second stop right behind it
     std::vector<Ev> events;
     std::vector<hipEvent_t> pool;
     struct Rec { double bytes; int pro; long R; int N, K; };
-    std::vector<Rec> each;  // the timed launches (PCB_TIMER_VERBOSE listing)
-    double bytes = 0.0;
+    std::vector<Rec> each;  // the timed category-0 launches (PCB_TIMER_VERBOSE listing)
+    double all_bytes = 0.0;   // every accounted launch since pcb_timer_start
+    long all_launches = 0;
+    // results of the last pcb_timer_stop, per category
+    long n[kCats] = {0, 0};
+    double ms[kCats] = {0.0, 0.0}, bytes[kCats] = {0.0, 0.0};
     hipEvent_t get()
     {
         if (!pool.empty()) {
@@ -47,8 +57,17 @@ struct Timer {
 } g_timer;
 }  // namespace
 
-// called by the gemm_nt entry points around their launch
-void pcb_timer_begin(hipStream_t st, hipEvent_t *stop)
+// called by every entry point: algorithmic bytes of the launch it enqueued
+void pcb_account(double bytes)
+{
+    if (!g_timer.armed) return;
+    std::lock_guard<std::mutex> lk(g_timer.mu);
+    g_timer.all_bytes += bytes;
+    g_timer.all_launches += 1;
+}
+
+// called by the timed entry points around their launch
+void pcb_timer_begin_cat(hipStream_t st, hipEvent_t *stop, int cat)
 {
     *stop = nullptr;
     if (!g_timer.on) return;
@@ -57,22 +76,28 @@ void pcb_timer_begin(hipStream_t st, hipEvent_t *stop)
     hipEvent_t a = g_timer.get(), b = g_timer.get(), c = g_timer.get();
     if (!a || !b || !c) return;
     (void)hipEventRecord(a, st);
-    g_timer.events.push_back({a, b, c});
+    g_timer.events.push_back({a, b, c, cat, 0.0});
     *stop = b;
 }
+void pcb_timer_begin(hipStream_t st, hipEvent_t *stop) { pcb_timer_begin_cat(st, stop, 0); }
 
 void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes, int pro, long R, int N, int K)
 {
+    pcb_account(bytes);
     if (!stop) return;
     (void)hipEventRecord(stop, st);
     std::lock_guard<std::mutex> lk(g_timer.mu);
     // An event is a packet of its own on the queue: elapsed(start, stop) holds the kernel PLUS the
     // processing of one event packet.  A third event recorded right behind `stop` measures exactly
     // that (nothing lies between them) and is subtracted when the samples are read.
-    if (!g_timer.events.empty() && g_timer.events.back().second == stop)
-        (void)hipEventRecord(g_timer.events.back().third, st);
-    g_timer.bytes += bytes;
-    g_timer.each.push_back({bytes, pro, R, N, K});
+    for (auto it = g_timer.events.rbegin(); it != g_timer.events.rend(); ++it) {
+        if (it->second == stop) {
+            (void)hipEventRecord(it->third, st);
+            it->bytes = bytes;
+            if (it->cat == 0) g_timer.each.push_back({bytes, pro, R, N, K});
+            break;
+        }
+    }
 }
 
 extern "C" int pcb_timer_start(void)
@@ -85,7 +110,8 @@ extern "C" int pcb_timer_start(void)
     }
     g_timer.events.clear();
     g_timer.each.clear();
-    g_timer.bytes = 0.0;
+    g_timer.all_bytes = 0.0;
+    g_timer.all_launches = 0;
     g_timer.armed = true;
     g_timer.on = true;
     return PCB_OK;
@@ -103,32 +129,51 @@ extern "C" int pcb_timer_stop(long *launches, double *milliseconds, double *byte
     std::lock_guard<std::mutex> lk(g_timer.mu);
     g_timer.on = false;
     g_timer.armed = false;
-    double ms = 0.0;
-    long n = 0;
+    for (int c = 0; c < kCats; ++c) {
+        g_timer.n[c] = 0;
+        g_timer.ms[c] = g_timer.bytes[c] = 0.0;
+    }
     const bool verbose = getenv("PCB_TIMER_VERBOSE") != nullptr;
     size_t i = 0;
     for (auto &p : g_timer.events) {
         float t = 0.0f, gap = 0.0f;
         if (hipEventSynchronize(p.third) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess &&
             hipEventElapsedTime(&gap, p.second, p.third) == hipSuccess) {
-            if (verbose) fprintf(stderr, "[pcb_timer] raw %.1f us, event packet %.1f us\n", t * 1e3, gap * 1e3);
+            if (verbose) fprintf(stderr, "[pcb_timer] cat %d raw %.1f us, event packet %.1f us\n", p.cat, t * 1e3, gap * 1e3);
             t = t > gap ? t - gap : 0.0f;
-            ms += t;
-            ++n;
-            if (verbose && i < g_timer.each.size())
+            g_timer.ms[p.cat] += t;
+            g_timer.bytes[p.cat] += p.bytes;
+            g_timer.n[p.cat] += 1;
+            if (verbose && p.cat == 0 && i < g_timer.each.size())
                 fprintf(stderr, "[pcb_timer] %zu pro=%d R=%ld N=%d K=%d: %.1f MB in %.1f us = %.2f TB/s\n", i,
                         g_timer.each[i].pro, g_timer.each[i].R, g_timer.each[i].N, g_timer.each[i].K,
                         g_timer.each[i].bytes / 1e6, t * 1e3, g_timer.each[i].bytes / (t * 1e-3) / 1e12);
         }
-        ++i;
+        if (p.cat == 0) ++i;
         g_timer.pool.push_back(p.first);
         g_timer.pool.push_back(p.second);
         g_timer.pool.push_back(p.third);
     }
     g_timer.events.clear();
-    if (launches) *launches = n;
-    if (milliseconds) *milliseconds = ms;
-    if (bytes) *bytes = g_timer.bytes;
+    if (launches) *launches = g_timer.n[0];
+    if (milliseconds) *milliseconds = g_timer.ms[0];
+    if (bytes) *bytes = g_timer.bytes[0];
+    return PCB_OK;
+}
+
+extern "C" int pcb_timer_read(int category, long *launches, double *milliseconds, double *bytes)
+{
+    std::lock_guard<std::mutex> lk(g_timer.mu);
+    if (category == -1) {  // every accounted launch between start and stop (not event-timed)
+        if (launches) *launches = g_timer.all_launches;
+        if (milliseconds) *milliseconds = 0.0;
+        if (bytes) *bytes = g_timer.all_bytes;
+        return PCB_OK;
+    }
+    if (category < 0 || category >= kCats) return PCB_ERR_INVALID_ARG;
+    if (launches) *launches = g_timer.n[category];
+    if (milliseconds) *milliseconds = g_timer.ms[category];
+    if (bytes) *bytes = g_timer.bytes[category];
     return PCB_OK;
 }
 
@@ -370,7 +415,7 @@ extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, co
         PCB_TRY(op.prep_zero(n, pd, cleared ? nullptr : stz, cleared ? 0 : stz_floats, stream));
         cleared = true;
     }
-    if (!cleared && hipMemsetAsync(stz, 0, stz_floats * sizeof(float), st) != hipSuccess) return PCB_ERR_LAUNCH;
+    if (!cleared && pcb_zero_async(stz, stz_floats * sizeof(float), st) != PCB_OK) return PCB_ERR_LAUNCH;
 
     const void *cur = x;
     for (int l = 0; l < L; ++l) {
@@ -489,10 +534,10 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
                 // local (the gradient all-reduce averages them like every other parameter gradient)
                 float *tot = row(stz, a, 0);
                 PCB_TRY(pcb_sum_slabs(sums, nparts, 2 * a.C, tot, stream));
-                if (hipMemcpyAsync(parts, tot, sizeof(float) * 2 * a.C, hipMemcpyDeviceToDevice, main_st) != hipSuccess)
+                if (pcb_copy_async(parts, tot, sizeof(float) * 2 * a.C, main_st) != PCB_OK)
                     return PCB_ERR_LAUNCH;
                 if (sync->allreduce(parts, 2 * a.C, sync->ctx) != 0) return PCB_ERR_LAUNCH;
-                if (sums == bsums && hipMemsetAsync(bsums, 0, sizeof(float) * 2 * a.C, main_st) != hipSuccess)
+                if (sums == bsums && pcb_zero_async(bsums, sizeof(float) * 2 * a.C, main_st) != PCB_OK)
                     return PCB_ERR_LAUNCH;  // what the finalize kernel does for a single atomically accumulated slab
                 sums = tot;
                 nparts = 1;
@@ -507,9 +552,9 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
             if (gathered && l == 0) {
                 // gathered layer: its input gradients are du (per source point) and dv (per centroid)
                 if (pooled && pool != ga.ns) return PCB_ERR_INVALID_ARG;
-                if (hipMemsetAsync(ga.u, 0, sizeof(float) * (size_t)ga.B * ga.N * a.C, main_st) != hipSuccess)
+                if (pcb_zero_async(ga.u, sizeof(float) * (size_t)ga.B * ga.N * a.C, main_st) != PCB_OK)
                     return PCB_ERR_LAUNCH;
-                if (ga.wx && hipMemsetAsync(ga.wx, 0, sizeof(float) * 3 * a.C * 33, main_st) != hipSuccess)
+                if (ga.wx && pcb_zero_async(ga.wx, sizeof(float) * 3 * a.C * 33, main_st) != PCB_OK)
                     return PCB_ERR_LAUNCH;
                 PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx,
                                             ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.u, ga.v, ga.wx, stream));

@@ -155,6 +155,7 @@ extern "C" int pcb_three_nn(const float *xyz1, const float *xyz2, int B, int N, 
         case 3: hipLaunchKernelGGL((three_nn_kernel<3>), grid, dim3(kThreads), 0, st, xyz1, xyz2, N, S, out_d2, out_idx); break;
         default: hipLaunchKernelGGL((three_nn_kernel<4>), grid, dim3(kThreads), 0, st, xyz1, xyz2, N, S, out_d2, out_idx); break;
     }
+    pcb_account(12.0 * ((double)N + S) * B + 12.0 * (double)k * N * B);
     return pcb_check_launch();
 }
 
@@ -172,6 +173,7 @@ extern "C" int pcb_interpolate(const float *feat, const float *d2, const int64_t
         case 3: hipLaunchKernelGGL((interpolate_kernel<3>), grid, dim3(256), 0, st, feat, d2, idx, N, S, C, out, out_w, total); break;
         default: hipLaunchKernelGGL((interpolate_kernel<4>), grid, dim3(256), 0, st, feat, d2, idx, N, S, C, out, out_w, total); break;
     }
+    pcb_account(4.0 * C * ((double)S + N) * B + 16.0 * (double)k * N * B);
     return pcb_check_launch();
 }
 
@@ -189,6 +191,7 @@ extern "C" int pcb_interpolate_bwd(const float *grad_out, const float *w, const 
         case 3: hipLaunchKernelGGL((interpolate_bwd_kernel<3>), grid, dim3(256), 0, st, grad_out, w, idx, N, S, C, grad_feat, total); break;
         default: hipLaunchKernelGGL((interpolate_bwd_kernel<4>), grid, dim3(256), 0, st, grad_out, w, idx, N, S, C, grad_feat, total); break;
     }
+    pcb_account(4.0 * C * ((double)N + (double)k * N) * B);
     return pcb_check_launch();
 }
 
@@ -337,6 +340,7 @@ int interpolate_rows(const void *feat, const float *d2, const int64_t *idx, int 
         case 3: hipLaunchKernelGGL((interpolate_rows_kernel<T, 3>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
         default: hipLaunchKernelGGL((interpolate_rows_kernel<T, 4>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
     }
+    pcb_account(sizeof(T) * (double)C * ((double)S + N) * B + 12.0 * (double)k * N * B);
     return pcb_check_launch();
 }
 
@@ -351,6 +355,7 @@ int interpolate_bwd_csr(const void *grad_rows, int ld, int col0, const float *w,
     hipLaunchKernelGGL(interpolate_bwd_csr_kernel<T>, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, (const T *)grad_rows, ld, col0, w, offsets, entries, N, S, C, k,
                        (T *)grad_feat, segments);
+    pcb_account(sizeof(T) * (double)C * ((double)k * N + S) * B + 8.0 * (double)k * N * B);
     return pcb_check_launch();
 }
 

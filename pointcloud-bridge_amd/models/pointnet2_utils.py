@@ -36,14 +36,31 @@ def index_points(points, idx):
     return ops.gather_rows(points, idx)
 
 
+_scene_shard = (0, 1)
+
+
+def set_scene_shard(rank, world):
+    """Data-parallel runs that split ONE global batch of scenes over `world` ranks (strong scaling):
+    every rank draws the start indices of the whole global batch from its CPU generator -- seeded
+    identically on all ranks -- and keeps the entries of its own scenes.  The sharded run then
+    consumes the reference's RNG stream (pointnet2_utils.py:69) exactly like a single process over the
+    global batch, so its samples, and with SyncBatchNorm its step, equal the single-process step."""
+    global _scene_shard
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    _scene_shard = (int(rank), int(world))
+
+
 def farthest_point_sample(xyz, npoint):
     """xyz [B,N,3] -> [B,npoint] int64 (reference :63-80).
 
     Consumes exactly one torch.randint(0, N, (B,)) from the CPU default generator, like the
-    reference (:69), so seeded runs sample the same start points."""
+    reference (:69), so seeded runs sample the same start points (see set_scene_shard for sharded
+    global batches)."""
     B, N, _ = xyz.shape
     ops._need_cuda(xyz)  # GPU only: fail here, before any staging copy
-    start = torch.randint(0, N, (B,), dtype=torch.long)
+    rank, world = _scene_shard
+    start = torch.randint(0, N, (B * world,), dtype=torch.long)[rank * B:(rank + 1) * B]
     # pinned staging + asynchronous copy: a pageable .to(device) would stall the host until the
     # stream has drained, three times per forward pass
     start = start.pin_memory().to(xyz.device, non_blocking=True)
@@ -199,7 +216,8 @@ class StaticSampling:
         (reference :69), staged through pinned memory into the static start buffers."""
         for lv in self.levels:
             B = lv["start"].shape[0]
-            lv["pinned"].copy_(torch.randint(0, lv["n_in"], (B,), dtype=torch.long))
+            rank, world = _scene_shard
+            lv["pinned"].copy_(torch.randint(0, lv["n_in"], (B * world,), dtype=torch.long)[rank * B:(rank + 1) * B])
             lv["start"].copy_(lv["pinned"], non_blocking=True)
 
     def compute(self, xyz):

@@ -58,10 +58,21 @@ def kernel_timer_enable(flag):
 
 
 def kernel_timer_stop():
-    """-> (launches, total milliseconds, algorithmic bytes) since kernel_timer_start; synchronises."""
+    """-> (launches, total milliseconds, algorithmic bytes) of the gemm_nt family since
+    kernel_timer_start; synchronises the recorded events."""
     import ctypes
     n, ms, by = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
     _lib.check(_lib.load().pcb_timer_stop(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), "pcb_timer_stop")
+    return n.value, ms.value, by.value
+
+
+def kernel_timer_read(category):
+    """After kernel_timer_stop: (launches, milliseconds, bytes) of category 0 (gemm_nt family), 1 (farthest
+    point sampling) or -1 (every launch of the library since kernel_timer_start: count and algorithmic
+    bytes, not event-timed)."""
+    import ctypes
+    n, ms, by = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _lib.check(_lib.load().pcb_timer_read(int(category), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), "pcb_timer_read")
     return n.value, ms.value, by.value
 
 

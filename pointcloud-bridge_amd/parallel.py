@@ -105,6 +105,120 @@ class FlatGradAllReduce:
                 p.grad = v
 
 
+class OverlappedGradAllReduce:
+    """The flat gradient all-reduce, started bucket by bucket WHILE the backward pass is still running.
+
+    The parameters are split into buckets in parameter order (by default one per top-level child
+    module: sa1, sa2, ..., the head).  Every parameter's gradient is copied into its slice of ONE
+    flat fp32 buffer the moment autograd has produced it (post-accumulate-grad hook); when a
+    bucket's last gradient has landed, its slice goes into an asynchronous all-reduce (RCCL runs it
+    on its own stream: the encoder's gradients are still being computed while the decoder's travel).
+    finish() waits for the collectives and returns the averaged flat gradient, laid out exactly like
+    parallel.FlatAdam's parameter buffer.  A parameter that received no gradient in a step counts as
+    zero (every rank then reduces the same layout).  With one rank the hooks only do the packing."""
+
+    def __init__(self, params, buckets=None, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        if any(p.dtype != torch.float32 for p in self.params):
+            raise TypeError("OverlappedGradAllReduce expects fp32 master parameters")
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        index = {id(p): i for i, p in enumerate(self.params)}
+        if buckets is None:
+            buckets = [self.params]
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.bucket_of = [None] * len(self.params)   # parameter -> bucket
+        self.ranges = []                               # bucket -> (first float, one past the last, parameters)
+        for b, plist in enumerate(buckets):
+            ids = sorted(index[id(p)] for p in plist if id(p) in index)
+            if not ids:
+                continue
+            if ids != list(range(ids[0], ids[-1] + 1)):
+                raise ValueError("a bucket must be a contiguous run of the parameter list")
+            k = len(self.ranges)
+            for i in ids:
+                self.bucket_of[i] = k
+            lo = self.offsets[ids[0]]
+            hi = self.offsets[ids[-1]] + self.params[ids[-1]].numel()
+            self.ranges.append((lo, hi, len(ids)))
+        if any(b is None for b in self.bucket_of):
+            raise ValueError("every parameter must belong to a bucket")
+        self.pending = [n for _, _, n in self.ranges]
+        self.landed = [False] * len(self.params)
+        self.works = []
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook(i)) for i, p in enumerate(self.params)]
+
+    @classmethod
+    def by_children(cls, module, group=None):
+        """One bucket per top-level child of `module` (registration order = parameter order)."""
+        params = [p for p in module.parameters() if p.requires_grad]
+        seen, buckets = set(), []
+        for child in module.children():
+            plist = [p for p in child.parameters() if p.requires_grad and id(p) not in seen]
+            seen.update(id(p) for p in plist)
+            if plist:
+                buckets.append(plist)
+        rest = [p for p in params if id(p) not in seen]
+        if rest:
+            buckets.append(rest)
+        return cls(params, buckets, group)
+
+    def _hook(self, i):
+        def hook(p):
+            self.landed[i] = True
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        """Bucket b is complete: ONE concatenation packs its gradients into the flat buffer (a missing
+        gradient counts as zero), then its slice starts travelling."""
+        lo, hi, _ = self.ranges[b]
+        members = [i for i, k in enumerate(self.bucket_of) if k == b]
+        torch.cat([(self.params[i].grad if self.params[i].grad is not None else torch.zeros_like(self.params[i])).reshape(-1)
+                   for i in members], out=self.flat[lo:hi])
+        for i in members:
+            self.params[i].grad = None  # the flat buffer is the gradient from here on
+        if self.world > 1:
+            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def zero(self):
+        """Call before every backward pass."""
+        for p in self.params:
+            p.grad = None
+        self.pending = [n for _, _, n in self.ranges]
+        self.landed = [False] * len(self.params)
+        self.works = []
+
+    def finish(self):
+        """After backward: reduce what has not been reduced yet, wait, average.  Returns the flat gradient."""
+        for i, ok in enumerate(self.landed):
+            if not ok:  # no gradient this step: counts as zeros, so that every rank reduces the same layout
+                self.landed[i] = True
+                b = self.bucket_of[i]
+                self.pending[b] -= 1
+                if self.pending[b] == 0:
+                    self._launch(b)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.world > 1:
+            self.flat.div_(self.world)
+        return self.flat
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+
 class FlatAdam:
     """torch.optim.Adam (the reference's optimiser, train_MulSca_PN2.py:125: Adam with L2 weight
     decay) over ONE flat fp32 buffer: the parameters become views of it, the gradients arrive as one

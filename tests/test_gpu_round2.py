@@ -285,4 +285,56 @@ def test_syncbatchnorm_two_ranks_equal_one_rank_global_batch(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = out.read_text().strip().splitlines()
-    assert len(lines) == 2 and all(": OK" in ln for ln in lines), lines
+    print("\n".join(lines))
+    assert len(lines) == 6 and all(": OK" in ln for ln in lines), lines
+
+
+def test_bench_two_ranks_strong_scaling_equal_the_one_rank_run(tmp_path):
+    """SURVEY 8(e) end to end through bench.py: ONE global batch of 4 scenes, (a) in one process, (b) split
+    over two ranks (gloo; both on this GPU; the launcher is a fresh child process) with SyncBatchNorm
+    inside the fused engine, FPS start indices drawn for the global batch on every rank
+    (pointnet2_utils.set_scene_shard) and the overlapped flat gradient all-reduce.  Same data, same
+    seeds, fp32 rows.  The first step's loss agrees to 1e-6 and its averaged gradient equals the
+    single-process gradient up to the branches ReLU / max-pool take at pre-activations within rounding
+    distance of a tie (the all-reduced statistics differ from the single process's in the last bit;
+    two identical single-process runs agree to 2e-6, tools/grad_noise.py; measured here: 99 % quantile
+    3.1e-4, relative L2 6.1e-3, worst entry 6.2e-3): 99 % of the entries within 1e-3 of the largest,
+    relative L2 error below 2e-2.  The global mean losses of 3 steps agree to 1e-3
+    and the parameters stay within the reach of Adam's sign-like first updates."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "3", "--warmup", "0", "--npoints", "2048", "--batch", "4", "--precision", "fp32",
+              "--no-cpu-baseline", "--no-extras", "--no-dropout", "--model", "pn2_msg"]
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--dump", one] + common,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(REPO, "bench.py"), "--gpus", "2",
+                        "--scaling", "strong", "--sync-bn", "--dump", two] + common,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    a, b = torch.load(one, weights_only=True), torch.load(two, weights_only=True)
+    print("losses", a["losses"], b["losses"])
+    np.testing.assert_allclose(b["losses"], a["losses"], rtol=1e-3)
+    ga, gb = a["first_grad"], b["first_grad"]
+    assert ga.numel() == gb.numel() > 0
+    gerr = float((ga - gb).abs().max() / ga.abs().max())
+    d = (ga - gb).abs()
+    q99 = float(d.kthvalue(int(d.numel() * 0.99))[0] / ga.abs().max())
+    l2 = float((ga - gb).norm() / ga.norm())
+    print("first-step gradient: max |d| / max |g| =", gerr, " 99 % quantile", q99, " relative L2", l2)
+    from pointcloud_bridge_amd.models.containers import PointNet2MSG
+    off, rows = 0, []
+    for name, prm in PointNet2MSG(5).named_parameters():
+        n = prm.numel()
+        rows.append((float((ga[off:off + n] - gb[off:off + n]).abs().max() / ga.abs().max()), name))
+        off += n
+    print("worst parameters:", sorted(rows, reverse=True)[:6])
+    for e, name in rows:
+        if name.endswith("weight") and ("convs" in name or "conv_blocks" in name or "final" in name or "fusion" in name or "attention" in name):
+            print(f"   {name:40s} {e:.2e}")
+    assert abs(a["losses"][0] - b["losses"][0]) < 1e-6 * abs(a["losses"][0])
+    assert q99 < 1e-3 and l2 < 2e-2 and gerr < 0.1
+    d = (a["flat"] - b["flat"]).abs()
+    print("params: mean |d|", float(d.mean()), "max |d|", float(d.max()))
+    assert float(d.mean()) < 1e-3 and float(d.max()) < 6.1e-3   # 3 steps x lr (1e-3) x 2 at most for a sign flip

@@ -75,6 +75,36 @@ def _worker(rank, world, port, tmp):
         ref_opt.step()
     for a, b in zip(model.parameters(), full2.parameters()):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    # the bench's overlapped form: gradients land in the flat buffer through hooks, every bucket's
+    # all-reduce starts when its last gradient has arrived (during the backward pass); a parameter
+    # without a gradient counts as zero.  Must give the same flat gradient as the one-shot reduce.
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(6, 8)
+            self.unused = nn.Linear(4, 4)     # never called: no gradient on any rank
+            self.b = nn.Sequential(nn.ReLU(), nn.Linear(8, 3))
+
+        def forward(self, x):
+            return self.b(self.a(x))
+
+    torch.manual_seed(3)
+    net = Net()
+    parallel.broadcast_parameters(net)
+    over = parallel.OverlappedGradAllReduce.by_children(net)
+    assert len(over.ranges) == 3
+    for step in range(2):
+        over.zero()
+        ((net(X[mine]) - Y[mine]) ** 2).mean().backward()
+        flat = over.finish().clone()
+        assert all(p.grad is None for p in net.parameters())   # moved into the flat buffer, bucket by bucket
+    over.close()
+    one = parallel.FlatGradAllReduce(net.parameters(), assign_views=False)
+    one.zero()
+    ((net(X[mine]) - Y[mine]) ** 2).mean().backward()
+    one.reduce()
+    torch.testing.assert_close(flat, one.flat, rtol=1e-6, atol=1e-7)
+    assert float(flat[over.ranges[1][0]:over.ranges[1][1]].abs().max()) == 0.0   # the unused layer's slice
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
