@@ -458,6 +458,314 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
     }
 }
 
+// ---- gemm_nt, eight-wave form -------------------------------------------------------------------
+// The 128 x 128 x 64 stages of gemm_nt_kernel run by 512 threads (4 x 2 waves, 32 rows x 64 columns
+// each), for the forward prologues (plain, BatchNorm+activation on load).  At the 168 registers
+// that three four-wave workgroups per CU leave a thread, the compiler reads every B fragment of the
+// four-wave kernel into the same four registers -- each MFMA waits for its own LDS read -- and the
+// per-column constants, fetched from global memory at the top of every stage, put an L2 round trip
+// on each stage's critical path.  Here a wave stages half as many chunks and holds half the
+// accumulators (fragments are double-buffered within 128 registers, 16 waves per CU), and the
+// constants come from LDS (all K columns, loaded once per workgroup).
+// Measured on the shapes of a pn2_msg step (tools/nt_bench.py): forward launches 5-25 % shorter.
+// What was tried and is NOT here: a second register set of staged operands (spills at any
+// occupancy that keeps 16 waves), 64-row tiles at 3 or 4 workgroups per CU (slower: twice the
+// weight traffic from L2).
+constexpr int N8_THREADS = 512;
+constexpr int N8_MAXK = 512;  // columns of constants held in LDS; longer rows use gemm_nt_kernel
+
+template <int PRO>
+struct ConstsLds {
+    float scale[8], shift[8], p[8], q[8];
+    // cst = [4][kpad] floats in LDS: scale | shift | p | q
+    __device__ __forceinline__ void load(const float *cst, int kpad, int c)
+    {
+        if (PRO == PRO_PLAIN) return;
+        rd8(cst + c, scale);
+        rd8(cst + kpad + c, shift);
+        if (PRO >= PRO_DY) {
+            rd8(cst + 2 * kpad + c, p);
+            rd8(cst + 3 * kpad + c, q);
+        }
+    }
+    static __device__ __forceinline__ void rd8(const float *src, float *dst)
+    {
+        const float4 a = *reinterpret_cast<const float4 *>(src);
+        const float4 b = *reinterpret_cast<const float4 *>(src + 4);
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+        dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+    }
+};
+
+// Raw<PRO>::finish with constants given as a ConstsLds (same arithmetic, same order)
+template <int PRO>
+__device__ __forceinline__ uint4 finish_with(const Raw<PRO> &r, const ConstsLds<PRO> &k, float slope)
+{
+    Consts<PRO> c;
+    if (PRO != PRO_PLAIN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            c.scale[i] = k.scale[i];
+            c.shift[i] = k.shift[i];
+            if (PRO >= PRO_DY) {
+                c.p[i] = k.p[i];
+                c.q[i] = k.q[i];
+            }
+        }
+    }
+    return r.finish(c, slope);
+}
+
+template <int PRO, int NA, int NB>
+struct Slot8 {
+    Raw<PRO> ra[NA];
+    uint4 rb[NB];
+    uint32_t keepb[NB];
+};
+
+template <int PRO, int STATS, int RED, int WM, int OCC>
+__global__ __launch_bounds__(WM * 128, OCC) void gemm_nt8_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
+                                                                           int N, int K, u16 *__restrict__ out,
+                                                                           float *__restrict__ sums, RedArgs red_arg)
+{
+    const Operand A = local_copy(A_arg);
+    const float a_slope = act_slope(A.act), red_slope = act_slope(red_arg.act);
+    RedArgs red;
+    red.y = red_arg.y; red.scale = red_arg.scale; red.shift = red_arg.shift;
+    red.mean = red_arg.mean; red.invstd = red_arg.invstd; red.act = red_arg.act;
+    // [A stage | B stage] in the main loop, per-wave 32 x 64 output staging in the epilogue (same size)
+    constexpr int BM = WM * 32, THREADS = WM * 128, AROWS = THREADS / 8, NA = BM / AROWS, NB = NT_BN / AROWS;
+    __shared__ __attribute__((aligned(16))) u16 smem[(BM + NT_BN) * NT_LD];
+    static_assert(2 * WM * 32 * (64 + 8) <= (BM + NT_BN) * NT_LD, "output staging must fit the stage buffers");
+    u16 *const As = smem;
+    u16 *const Bs = smem + BM * NT_LD;
+    __shared__ float ssum[WM * 2 * NT_BN];                                            // [wm][s|q][column]
+    __shared__ __attribute__((aligned(16))) float rconst[RED ? 4 * NT_BN : 4];      // RED: constants of the layer below
+    __shared__ __attribute__((aligned(16))) float cst[PRO == PRO_PLAIN ? 4 : (PRO == PRO_BNACT ? 2 : 4) * N8_MAXK];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.y * NT_BN;
+    const int chunk = t & 7;   // 8-column chunk inside a BK stage
+    const int rrow = t >> 3;   // 0..AROWS-1
+    const long tiles_m = (R + BM - 1) / BM;
+    constexpr int OLD = 64 + 8;  // output staging row stride
+
+    long tile = blockIdx.x;
+    if (tile >= tiles_m) {
+        if ((STATS || RED) && t < NT_BN && n0 + t < N) {
+            sums[((long)blockIdx.x * 2 + 0) * N + n0 + t] = 0.0f;
+            sums[((long)blockIdx.x * 2 + 1) * N + n0 + t] = 0.0f;
+        }
+        return;
+    }
+    const int kpad = K;  // cst row length (K % 8 == 0)
+    if (PRO != PRO_PLAIN) {
+        for (int i = t; i < K; i += THREADS) {
+            cst[i] = A.scale[i];
+            cst[kpad + i] = A.shift[i];
+            if (PRO >= PRO_DY) {
+                cst[2 * kpad + i] = A.p[i];
+                cst[3 * kpad + i] = A.q[i];
+            }
+        }
+    }
+    if (STATS || RED)
+        for (int i = t; i < WM * 2 * NT_BN; i += THREADS) ssum[i] = 0.0f;
+    if (RED && t < NT_BN) {
+        const bool ok = n0 + t < N;
+        rconst[0 * NT_BN + t] = ok ? red.scale[n0 + t] : 0.0f;
+        rconst[1 * NT_BN + t] = ok ? red.shift[n0 + t] : 0.0f;
+        rconst[2 * NT_BN + t] = ok ? red.mean[n0 + t] : 0.0f;
+        rconst[3 * NT_BN + t] = ok ? red.invstd[n0 + t] : 0.0f;
+    }
+
+    f32x16 acc[2];
+    float st_s[2] = {0.0f, 0.0f}, st_q[2] = {0.0f, 0.0f};
+
+    Slot8<PRO, NA, NB> s0;
+    long ft = tile;  // the (tile, k-stage) pair the next fetch loads
+    int fk = 0;
+    auto fetch = [&](Slot8<PRO, NA, NB> &s) {
+        if (ft < tiles_m) {
+            const int kc = fk + chunk * 8;
+            const long mb = ft * BM;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) s.ra[i].load(A, mb + rrow + AROWS * i, kc, R, K);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = n0 + rrow + AROWS * i;
+                s.rb[i] = *reinterpret_cast<const uint4 *>(Bw + (long)(n < N ? n : N - 1) * K + (kc < K ? kc : 0));
+                s.keepb[i] = (n < N && kc < K) ? 0xffffffffu : 0u;
+            }
+        }
+        fk += NT_BK;
+        if (fk >= K) {
+            fk = 0;
+            ft += gridDim.x;
+        }
+    };
+    fetch(s0);
+    __syncthreads();  // cst, ssum, rconst
+
+    auto stage = [&](Slot8<PRO, NA, NB> &s, int k0) {
+        ConstsLds<PRO> ka;
+        ka.load(cst, kpad, (k0 + chunk * 8 < K) ? k0 + chunk * 8 : 0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            *reinterpret_cast<uint4 *>(&As[(rrow + AROWS * i) * NT_LD + chunk * 8]) = finish_with<PRO>(s.ra[i], ka, a_slope);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            *reinterpret_cast<uint4 *>(&Bs[(rrow + AROWS * i) * NT_LD + chunk * 8]) =
+                make_uint4(s.rb[i].x & s.keepb[i], s.rb[i].y & s.keepb[i], s.rb[i].z & s.keepb[i], s.rb[i].w & s.keepb[i]);
+        __syncthreads();
+        fetch(s);  // the registers just emptied take the next stage: its loads fly under the MFMAs below
+        bf16x8 fa[2], fb[2][2];
+        auto frags = [&](int buf, int ks) {
+            const int kk = ks * 16 + (lane >> 5) * 8;
+            fa[buf] = *reinterpret_cast<const bf16x8 *>(&As[(wm * 32 + (lane & 31)) * NT_LD + kk]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fb[buf][j] = *reinterpret_cast<const bf16x8 *>(&Bs[(wn * 64 + j * 32 + (lane & 31)) * NT_LD + kk]);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < NT_BK / 16; ++ks) {
+            if (ks + 1 < NT_BK / 16) frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fb[ks & 1][j], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+
+    for (; tile < tiles_m; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+        for (int k0 = 0; k0 < K; k0 += NT_BK) stage(s0, k0);
+        const long m0 = tile * BM;
+        u16 *const stg = smem + wave * (32 * OLD);
+        const long rows_here = R - m0 < BM ? R - m0 : BM;
+        const __amdgpu_buffer_rsrc_t orsrc =
+            __builtin_amdgcn_make_buffer_rsrc(out + m0 * N, 0, (int)(rows_here * N * 2), 0x00020000);
+        uint4 yraw[RED ? 4 : 1];
+        if (RED) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = v * 64 + lane;  // 256 chunks: 32 rows x 8 chunks of 8 columns
+                const long r = m0 + wm * 32 + (ch >> 3);
+                const int n = n0 + wn * 64 + (ch & 7) * 8;
+                yraw[v] = *reinterpret_cast<const uint4 *>(red.y + (r < R ? r : R - 1) * N + (n < N ? n : 0));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float sv = 0.0f, sq = 0.0f;
+            float bj = 0.0f;
+            if (!STATS && !RED && red_arg.bias) {
+                const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+                bj = n < N ? red_arg.bias[n] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const u16 h = f2bf((!STATS && !RED) ? acc[j][i] + bj : acc[j][i]);
+                stg[rr * OLD + j * 32 + (lane & 31)] = h;
+                if (STATS) {
+                    const float v = bf2f(h);
+                    sv += v;
+                    sq = fmaf(v, v, sq);
+                }
+            }
+            if (STATS) {
+                st_s[j] += sv;
+                st_q[j] += sq;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        float rs1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rs2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ch = v * 64 + lane;
+            const int rr = ch >> 3, cc = (ch & 7) * 8;
+            const long r = m0 + wm * 32 + rr;
+            const int n = n0 + wn * 64 + cc;
+            const uint4 o = *reinterpret_cast<const uint4 *>(&stg[rr * OLD + cc]);
+            const int off = (r < R && n < N) ? (int)(((long)(wm * 32 + rr) * N + n) * 2) : -1;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{o.x, o.y, o.z, o.w}, orsrc, off, 0, 0);
+            if (RED) {
+                float dz[8], yv[8];
+                unpack8(o, dz);
+                unpack8(yraw[v], yv);
+                const int c8 = wn * 64 + (lane & 7) * 8;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(&rconst[0 * NT_BN + c8 + 4 * h]);
+                    const float4 sh = *reinterpret_cast<const float4 *>(&rconst[1 * NT_BN + c8 + 4 * h]);
+                    const float4 mu = *reinterpret_cast<const float4 *>(&rconst[2 * NT_BN + c8 + 4 * h]);
+                    const float4 is = *reinterpret_cast<const float4 *>(&rconst[3 * NT_BN + c8 + 4 * h]);
+                    const float rsc[4] = {sc.x, sc.y, sc.z, sc.w}, rsh[4] = {sh.x, sh.y, sh.z, sh.w};
+                    const float rmu[4] = {mu.x, mu.y, mu.z, mu.w}, ris[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = 4 * h + i;
+                        const float du = dz[e] * act_grad(fmaf(yv[e], rsc[i], rsh[i]), red_slope);
+                        rs1[e] += du;
+                        rs2[e] = fmaf(du, (yv[e] - rmu[i]) * ris[i], rs2[e]);
+                    }
+                }
+            }
+        }
+        if (RED) {
+            // lanes l, l+8, ..., l+56 share their 8 columns; lanes 0..7 add into the wave's slab
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                rs1[i] += __shfl_xor(rs1[i], 8);
+                rs1[i] += __shfl_xor(rs1[i], 16);
+                rs1[i] += __shfl_xor(rs1[i], 32);
+                rs2[i] += __shfl_xor(rs2[i], 8);
+                rs2[i] += __shfl_xor(rs2[i], 16);
+                rs2[i] += __shfl_xor(rs2[i], 32);
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    ssum[(wm * 2 + 0) * NT_BN + wn * 64 + lane * 8 + i] += rs1[i];
+                    ssum[(wm * 2 + 1) * NT_BN + wn * 64 + lane * 8 + i] += rs2[i];
+                }
+            }
+        }
+        __syncthreads();  // the next stage's LDS writes must not overtake another wave's read-back
+    }
+    if (STATS || RED) {
+#pragma unroll
+        for (int j = 0; j < (STATS ? 2 : 0); ++j) {
+            const float s2 = st_s[j] + __shfl_xor(st_s[j], 32);
+            const float q2 = st_q[j] + __shfl_xor(st_q[j], 32);
+            if (lane < 32) {
+                ssum[(wm * 2 + 0) * NT_BN + wn * 64 + j * 32 + lane] = s2;
+                ssum[(wm * 2 + 1) * NT_BN + wn * 64 + j * 32 + lane] = q2;
+            }
+        }
+        __syncthreads();
+        if (t < NT_BN && n0 + t < N) {
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                a += ssum[(w * 2 + 0) * NT_BN + t];
+                b += ssum[(w * 2 + 1) * NT_BN + t];
+            }
+            sums[((long)blockIdx.x * 2 + 0) * N + n0 + t] = a;
+            sums[((long)blockIdx.x * 2 + 1) * N + n0 + t] = b;
+        }
+    }
+}
+
 // ---- gemm_nt with the transformed A tile resident in LDS -------------------------------------
 // For the input-gradient GEMMs whose output is wider than one 128-column tile (N = 264: the layers
 // fed by grouped / concatenated rows) the plain kernel would rebuild A' = dy(dz, y) once per column
@@ -695,6 +1003,14 @@ void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, 
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)(sums ? nparts : pcb_nt_grid_x(PRO, R, N, pcb_busy_cus())), ny);
     RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    if (PRO <= PRO_BNACT && K <= N8_MAXK) {
+        // forward prologues: the eight-wave form, two workgroups per CU
+        if (sums)
+            hipLaunchKernelGGL((gemm_nt8_kernel<PRO, 1, 0, 4, 4>), grid, dim3(512), 0, st, A, Bw, R, N, K, out, sums, none);
+        else
+            hipLaunchKernelGGL((gemm_nt8_kernel<PRO, 0, 0, 4, 4>), grid, dim3(512), 0, st, A, Bw, R, N, K, out, sums, none);
+        return;
+    }
     if (red && PRO >= PRO_DY)
         hipLaunchKernelGGL((gemm_nt_kernel<PRO, 0, (PRO >= PRO_DY)>), grid, dim3(256), 0, st, A, Bw, R, N, K, out, sums, *red);
     else if (sums)
@@ -833,8 +1149,12 @@ extern "C" int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);
-    hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out,
-                       (float *)nullptr, epi);
+    if (K <= N8_MAXK)
+        hipLaunchKernelGGL((gemm_nt8_kernel<PRO_PLAIN, 0, 0, 4, 4>), grid, dim3(512), 0, st, A, (const u16 *)w, R, N, K,
+                           (u16 *)out, (float *)nullptr, epi);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out,
+                           (float *)nullptr, epi);
     pcb_timer_end(st, timed, nt_bytes(PRO_PLAIN, R, N, K, 0), PRO_PLAIN, R, N, K);
     return pcb_check_launch();
 }

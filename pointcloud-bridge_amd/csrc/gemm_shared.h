@@ -16,8 +16,7 @@ constexpr int PCB_MAX_SLABS = 768;  // upper bound of a gemm_nt launch's workgro
 int pcb_busy_cus();
 
 // Preferred number of workgroups along x (= statistics slabs) of a gemm_nt launch: persistent over
-// row tiles, as many as are resident at once -- 3 per CU for the forward prologues, 2 for the
-// register-heavier backward ones -- less what `busy_cus` other CUs are taken.  Never more than
+// row tiles, as many as are resident at once -- 2 per CU -- less what `busy_cus` other CUs are taken.  Never more than
 // PCB_MAX_SLABS, never more than the row tiles.
 long pcb_nt_grid_x(int pro, long R, int N, int busy_cus);
 

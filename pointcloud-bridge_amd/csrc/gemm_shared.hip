@@ -56,8 +56,19 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch ba
     for (long e0 = (long)blockIdx.x * 64; e0 < r.elems; e0 += (long)gridDim.x * 64) {
         const long e = e0 + ex;
         float a = 0.0f;
-        if (e < r.elems)
-            for (int s = sy; s < r.splits; s += 16) a += r.part[(long)s * r.elems + e];
+        if (e < r.elems) {
+            // eight splits' loads in flight per step, adds in split order
+            for (int s0 = sy; s0 < r.splits; s0 += 16 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sp = s0 + 16 * u;
+                    v[u] = sp < r.splits ? r.part[(long)sp * r.elems + e] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+        }
         red[sy][ex] = a;
         __syncthreads();
         if (sy == 0 && e < r.elems) {
@@ -105,9 +116,20 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(float *__restrict
     const int c = blockIdx.x * 32 + cl;
     float s1 = 0.0f, s2 = 0.0f;
     if (c < C) {
-        for (int k = pl; k < nparts; k += 32) {
-            s1 += sums[((long)k * 2 + 0) * C + c];
-            s2 += sums[((long)k * 2 + 1) * C + c];
+        // eight slabs' loads in flight per step, adds in slab order (see bn_finalize_kernel)
+        for (int k0 = pl; k0 < nparts; k0 += 32 * 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 32 * u;
+                a[u] = k < nparts ? sums[((long)k * 2 + 0) * C + c] : 0.0f;
+                b[u] = k < nparts ? sums[((long)k * 2 + 1) * C + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s1 += a[u];
+                s2 += b[u];
+            }
         }
     }
     red[0][pl][cl] = s1;
@@ -226,7 +248,7 @@ int prep_weights(int n, const long long *desc, float *zero, long zero_n, void *s
         if (a.l[i].C * a.l[i].kp > most) most = a.l[i].C * a.l[i].kp;
     }
     int gx = (most + 255) / 256;
-    if (gx > 64) gx = 64;
+    if (gx > 256) gx = 256;
     hipLaunchKernelGGL(prep_weights_kernel<T>, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
     return pcb_check_launch();
 }
@@ -304,11 +326,11 @@ long pcb_nt_grid_x(int pro, long R, int N, int busy_cus)
 {
     const long tiles = (R + PCB_NT_BM - 1) / PCB_NT_BM;
     const long ny = (N + PCB_NT_BN - 1) / PCB_NT_BN;
-    static const long fwd_chip = grid_knob("PCB_NT_FWD_GRID", 768);
+    static const long fwd_chip = grid_knob("PCB_NT_FWD_GRID", 512);
     static const long bwd_chip = grid_knob("PCB_NT_BWD_GRID", 512);
-    // while another kernel holds CUs the persistent grids leave them alone: 3 forward / 2 backward
-    // workgroups fit a CU
-    long chip = pro <= PCB_PRO_BNACT ? fwd_chip - 3L * busy_cus : bwd_chip - 2L * busy_cus;
+    // while another kernel holds CUs the persistent grids leave them alone: 2 workgroups fit a CU
+    // (512 threads each in the forward kernels, 256 in the register-heavier backward ones)
+    long chip = (pro <= PCB_PRO_BNACT ? fwd_chip : bwd_chip) - 2L * busy_cus;
     if (chip < 64) chip = 64;
     const long resident = chip / ny > 0 ? chip / ny : 1;
     return tiles < resident ? tiles : resident;

@@ -137,9 +137,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (training && c < C) {
-        for (int k = pl; k < nparts; k += 32) {  // sums is [nparts][2][C]
-            s1 += (double)sums[((long)k * 2 + 0) * C + c];
-            s2 += (double)sums[((long)k * 2 + 1) * C + c];
+        // sums is [nparts][2][C]; eight slabs' loads are issued before the first add (the adds keep
+        // their order): a dependent load per step made this 10 us kernel a chain of L2 round trips
+        for (int k0 = pl; k0 < nparts; k0 += 32 * 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 32 * u;
+                a[u] = k < nparts ? sums[((long)k * 2 + 0) * C + c] : 0.0f;
+                b[u] = k < nparts ? sums[((long)k * 2 + 1) * C + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s1 += (double)a[u];
+                s2 += (double)b[u];
+            }
         }
     }
     red[0][pl][cl] = s1;
