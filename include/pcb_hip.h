@@ -573,6 +573,21 @@ int pcb_scene_max_bwd_bf16(const void *g, const int *arg, int B, int N, int C, v
 int pcb_scene_max_bwd_f32(const void *g, const int *arg, int B, int N, int C, void *dz, void *stream);
 
 /*
+ * Feature levels concatenated along channels with nearest repetition of the coarser ones -- replaces
+ * MultiScaleFeatureFusion's F.interpolate(level, size=N) + torch.cat (models/model.py:150-170) for levels of
+ * S_l rows per scene with r_l = N / S_l a power of two (nearest source of fine row i: coarse row i / r_l):
+ *   pcb_repeat_concat_*      out[i, col_l + c] = src_l[i / rep[l], c]          out [rows, sum width], one pass
+ *   pcb_repeat_concat_bwd_*  dsrc_l[s, c] = sum_{j < rep[l]} g[s*rep[l] + j, col_l + c]   (fp32 sums, one pass;
+ *                            a NULL dsrc_l is skipped)
+ * n <= 4 levels, src_l [rows / rep[l], width[l]] rows of the entry point's type, width[l] % 8 == 0 (bf16) /
+ * % 4 == 0 (fp32), rows % rep[l] == 0 (scene boundaries need no argument: rep[l] divides the rows per scene).
+ */
+int pcb_repeat_concat_bf16(int n, const void *const *src, const int *rep, const int *width, long rows, void *out, void *stream);
+int pcb_repeat_concat_f32(int n, const void *const *src, const int *rep, const int *width, long rows, void *out, void *stream);
+int pcb_repeat_concat_bwd_bf16(int n, const void *g, const int *rep, const int *width, long rows, void *const *dsrc, void *stream);
+int pcb_repeat_concat_bwd_f32(int n, const void *g, const int *rep, const int *width, long rows, void *const *dsrc, void *stream);
+
+/*
  * A whole stack of L <= PCB_STACK_MAX_LAYERS shared-MLP layers  x -> act(BN(x W^T + b))  [-> max over
  * each `pool` consecutive rows]  enqueued from ONE call -- the loop the reference writes as
  *   for i, conv in enumerate(self.mlp_convs): new_points = F.relu(self.mlp_bns[i](conv(new_points)))

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch ba
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int sp = s0 + 16 * u;
-                    v[u] = sp < r.splits ? r.part[(long)sp * r.elems + e] : 0.0f;
+                    const float x = r.part[(long)(sp < r.splits ? sp : r.splits - 1) * r.elems + e];
+                    v[u] = sp < r.splits ? x : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) a += v[u];
@@ -121,9 +122,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(float *__restrict
             float a[8], b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int k = k0 + 32 * u;
-                a[u] = k < nparts ? sums[((long)k * 2 + 0) * C + c] : 0.0f;
-                b[u] = k < nparts ? sums[((long)k * 2 + 1) * C + c] : 0.0f;
+                const int k = k0 + 32 * u, kc = k < nparts ? k : nparts - 1;
+                const float va = sums[((long)kc * 2 + 0) * C + c], vb = sums[((long)kc * 2 + 1) * C + c];
+                a[u] = k < nparts ? va : 0.0f;
+                b[u] = k < nparts ? vb : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {

@@ -143,9 +143,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
             float a[8], b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int k = k0 + 32 * u;
-                a[u] = k < nparts ? sums[((long)k * 2 + 0) * C + c] : 0.0f;
-                b[u] = k < nparts ? sums[((long)k * 2 + 1) * C + c] : 0.0f;
+                // unconditional loads from a clamped slab (a load under a branch is waited for on the spot)
+                const int k = k0 + 32 * u, kc = k < nparts ? k : nparts - 1;
+                const float va = sums[((long)kc * 2 + 0) * C + c], vb = sums[((long)kc * 2 + 1) * C + c];
+                a[u] = k < nparts ? va : 0.0f;
+                b[u] = k < nparts ? vb : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {

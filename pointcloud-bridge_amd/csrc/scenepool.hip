@@ -259,6 +259,116 @@ int scene_max_bwd(const void *g, const int *arg, int B, int N, int C, void *dz, 
     return pcb_check_launch();
 }
 
+
+// ---- concatenation of feature levels with nearest repetition -----------------------------------
+// MultiScaleFeatureFusion (models/model.py:150-170): F.interpolate(level, size=N) of the coarser
+// decoder levels followed by torch.cat along channels.  With S_l | N and N / S_l a power of two the
+// nearest source of fine row i is coarse row i / r_l (models/containers.py), so
+//     out[i, col_l + c] = src_l[i / r_l, c]
+// in ONE pass over the output (ATen: one strided copy per level), and backward
+//     dsrc_l[s, c] = sum_{j < r_l} g[s * r_l + j, col_l + c]     (fp32 sums, rounded once)
+// in one pass over the gradient (ATen: a strided slice made contiguous per level plus one reduction
+// kernel per repeated level).
+constexpr int kMaxLevels = 4;
+struct RepeatLevels {
+    const void *src[kMaxLevels];
+    void *dst[kMaxLevels];      // backward outputs
+    int rep[kMaxLevels];        // r_l >= 1
+    int chunk0[kMaxLevels + 1]; // first 16-byte chunk of level l in an output row; [n] = chunks per row
+    int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void repeat_concat_kernel(RepeatLevels lv, long rows, uint4 *__restrict__ out)
+{
+    const int CT = lv.chunk0[lv.n];
+    const long total = rows * CT;
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+        const long i = e / CT;
+        const int cc = (int)(e - i * CT);
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxLevels; ++k) l += (k < lv.n && cc >= lv.chunk0[k]) ? 1 : 0;
+        const int w = lv.chunk0[l + 1] - lv.chunk0[l];
+        out[e] = reinterpret_cast<const uint4 *>(lv.src[l])[(i / lv.rep[l]) * w + (cc - lv.chunk0[l])];
+    }
+}
+
+// one thread per (coarse row, chunk) of one level (blockIdx.y = level)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void repeat_concat_bwd_kernel(RepeatLevels lv, long rows, const uint4 *__restrict__ g)
+{
+    constexpr int E = RowVec<T>::E;
+    const int l = blockIdx.y;
+    const int CT = lv.chunk0[lv.n];
+    const int w = lv.chunk0[l + 1] - lv.chunk0[l], r = lv.rep[l];
+    const long total = rows / r * w;
+    uint4 *const dst = reinterpret_cast<uint4 *>(lv.dst[l]);
+    if (!dst) return;
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+        const long s = e / w;
+        const int cc = (int)(e - s * w);
+        const uint4 *src = g + (s * r) * CT + lv.chunk0[l] + cc;
+        if (r == 1) {
+            dst[e] = *src;
+            continue;
+        }
+        float acc[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) acc[i] = 0.0f;
+        for (int j = 0; j < r; ++j) {
+            float f[E];
+            RowVec<T>::unpack(src[(long)j * CT], f);
+#pragma unroll
+            for (int i = 0; i < E; ++i) acc[i] += f[i];
+        }
+        dst[e] = RowVec<T>::pack(acc);
+    }
+}
+
+template <typename T>
+int repeat_concat(int n, const void *const *src, void *const *dst, const int *rep, const int *width, long rows, void *io,
+                  bool backward, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (n < 1 || n > kMaxLevels || !src == !dst || !rep || !width || rows <= 0 || !io) return PCB_ERR_INVALID_ARG;
+    RepeatLevels lv;
+    lv.n = n;
+    int col = 0, most = 0;
+    for (int l = 0; l < kMaxLevels; ++l) {
+        lv.src[l] = nullptr;
+        lv.dst[l] = nullptr;
+        lv.rep[l] = 1;
+    }
+    for (int l = 0; l < n; ++l) {
+        if (width[l] <= 0 || width[l] % E || rep[l] < 1 || rows % rep[l]) return PCB_ERR_UNSUPPORTED;
+        if (!backward && !src[l]) return PCB_ERR_INVALID_ARG;
+        lv.src[l] = backward ? nullptr : src[l];
+        lv.dst[l] = backward ? dst[l] : nullptr;
+        lv.rep[l] = rep[l];
+        lv.chunk0[l] = col;
+        col += width[l] / E;
+        const long per = rows / rep[l] * (width[l] / E);
+        most = per > most ? (int)(per > (1L << 30) ? (1L << 30) : per) : most;
+    }
+    for (int l = n; l <= kMaxLevels; ++l) lv.chunk0[l] = col;
+    hipStream_t st = (hipStream_t)stream;
+    if (!backward) {
+        const long total = rows * col;
+        long blocks = (total + kThreads - 1) / kThreads;
+        blocks = blocks > 8192 ? 8192 : blocks;
+        hipLaunchKernelGGL(repeat_concat_kernel<T>, dim3((unsigned)blocks), dim3(kThreads), 0, st, lv, rows, (uint4 *)io);
+        pcb_account(2.0 * total * 16);
+    } else {
+        long blocks = ((long)most + kThreads - 1) / kThreads;
+        blocks = blocks > 4096 ? 4096 : blocks;
+        hipLaunchKernelGGL(repeat_concat_bwd_kernel<T>, dim3((unsigned)blocks, (unsigned)n), dim3(kThreads), 0, st, lv, rows,
+                           (const uint4 *)io);
+        pcb_account(1.2 * rows * col * 16);
+    }
+    return pcb_check_launch();
+}
+
 }  // namespace
 
 extern "C" {
@@ -303,6 +413,23 @@ int pcb_scene_max_bwd_bf16(const void *g, const int *arg, int B, int N, int C, v
 int pcb_scene_max_bwd_f32(const void *g, const int *arg, int B, int N, int C, void *dz, void *stream)
 {
     return scene_max_bwd<float>(g, arg, B, N, C, dz, stream);
+}
+
+int pcb_repeat_concat_bf16(int n, const void *const *src, const int *rep, const int *width, long rows, void *out, void *stream)
+{
+    return repeat_concat<pcb_bf16>(n, src, nullptr, rep, width, rows, out, false, stream);
+}
+int pcb_repeat_concat_f32(int n, const void *const *src, const int *rep, const int *width, long rows, void *out, void *stream)
+{
+    return repeat_concat<float>(n, src, nullptr, rep, width, rows, out, false, stream);
+}
+int pcb_repeat_concat_bwd_bf16(int n, const void *g, const int *rep, const int *width, long rows, void *const *dsrc, void *stream)
+{
+    return repeat_concat<pcb_bf16>(n, nullptr, dsrc, rep, width, rows, (void *)g, true, stream);
+}
+int pcb_repeat_concat_bwd_f32(int n, const void *g, const int *rep, const int *width, long rows, void *const *dsrc, void *stream)
+{
+    return repeat_concat<float>(n, nullptr, dsrc, rep, width, rows, (void *)g, true, stream);
 }
 
 }  // extern "C"

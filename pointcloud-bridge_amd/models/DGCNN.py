@@ -103,7 +103,7 @@ class DGCNN(nn.Module):
             # W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i: per-point products, gathered by the graph
             # (rowmlp.gathered_mlp); the [B*N*k, 2D] edge tensor is never written
             w = block[0].weight.view(block[0].out_channels, 2 * D)
-            wa, wb = w[:, :D], w[:, D:]
+            wa, wb = rowmlp.split_cols(w, D)
             xr = x.reshape(B * N, D)
             y = rowmlp.gathered_mlp([block[0]], [block[1]], rowmlp.point_linear(xr, wa),
                                     rowmlp.point_linear(xr, wb - wa), idx, rowmlp.ACT_LEAKY, pool=k)

@@ -109,9 +109,10 @@ class MultiScaleFeatureFusion(nn.Module):
         """[B,C_i,S_i] levels -> [B, N, 3*out] channels-last rows (nearest resampling along the
         point axis, exactly F.interpolate(feat, size=N) of models/model.py:164)."""
         n = features_list[2].shape[2]
-        outs = []
+        outs, reps = [], []
+        B = features_list[0].shape[0]
         for f, conv in zip(features_list, self.convs):
-            B, _, S = f.shape
+            _, _, S = f.shape
             rows = _channels_last(f)
             r = n // S
             if S != n and n % S == 0 and (r & (r - 1)) == 0:
@@ -123,54 +124,23 @@ class MultiScaleFeatureFusion(nn.Module):
                     # on the S coarse rows (r times less GEMM work, forward and backward) and
                     # repeat its output.  Only the sample count of the unbiased running variance
                     # differs, which stat_repeat restores.
-                    o = rowmlp.conv_bn_act(conv[0], conv[1], rows.reshape(B * S, -1), rowmlp.ACT_RELU, stat_repeat=r)
-                    outs.append(o.view(B, S, 1, -1).expand(B, S, r, o.shape[1]))  # repeated on write below
+                    outs.append(rowmlp.conv_bn_act(conv[0], conv[1], rows.reshape(B * S, -1), rowmlp.ACT_RELU, stat_repeat=r))
+                    reps.append(r)  # repeated on write below
                     continue
                 rows = rows.unsqueeze(2).expand(B, S, r, rows.shape[2]).reshape(B, n, rows.shape[2])
             elif S != n:
                 ramp = torch.arange(S, dtype=torch.float32, device=f.device).view(1, 1, S)
                 src = F.interpolate(ramp, size=n).view(n).long()  # the very index map F.interpolate uses
                 rows = rows.index_select(1, src)
-            outs.append(_seq_rows(conv, rows.reshape(B * n, -1)).view(B, n, -1))
-        if all(o.dim() == 3 for o in outs):
-            return torch.cat(outs, dim=2)
-        return _RepeatConcat.apply(n, *outs)
-
-
-class _RepeatConcat(torch.autograd.Function):
-    """cat along channels of levels given as [B,n,C] rows or as [B,S,r,C] views of coarse rows
-    repeated r = n/S times: each level is written once, broadcast over r, straight into its column
-    block of the [B,n,sum C] buffer; backward hands every level its block of the gradient, summed
-    over the r repeats (no full-size intermediate in either direction)."""
-
-    @staticmethod
-    def forward(ctx, n, *levels):
-        B = levels[0].shape[0]
-        fused = torch.empty(B, n, sum(o.shape[-1] for o in levels), dtype=levels[0].dtype, device=levels[0].device)
-        col = 0
-        for o in levels:
-            c = o.shape[-1]
-            if o.dim() == 4:
-                fused.view(B, o.shape[1], o.shape[2], -1)[..., col:col + c] = o
-            else:
-                fused[..., col:col + c] = o
-            col += c
-        ctx.shapes = [tuple(o.shape) for o in levels]
-        return fused
-
-    @staticmethod
-    def backward(ctx, g):
-        grads, col = [], 0
-        B = g.shape[0]
-        for shp in ctx.shapes:
-            c = shp[-1]
-            if len(shp) == 4:
-                # the level was an expand() of [B,S,1,C]: autograd sums a [B,S,r,C] gradient over r
-                grads.append(g.view(B, shp[1], shp[2], -1)[..., col:col + c])
-            else:
-                grads.append(g[..., col:col + c])
-            col += c
-        return (None, *grads)
+            outs.append(_seq_rows(conv, rows.reshape(B * n, -1)))
+            reps.append(1)
+        q = rowmlp.mode().q
+        if all(r == 1 for r in reps) or any(o.shape[1] % q for o in outs) or len(outs) > 4:
+            return torch.cat([o.view(B, n // r, 1, -1).expand(B, n // r, r, o.shape[1]).reshape(B, n, -1)
+                              for o, r in zip(outs, reps)], dim=2)
+        # one pass writes every level, broadcast over its repeats, into its column block; backward hands every
+        # level its block of the gradient summed over the repeats (rowmlp.repeat_concat)
+        return rowmlp.repeat_concat(outs, reps).view(B, n, -1)
 
 
 class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):

@@ -379,8 +379,9 @@ def _grouped_mlp(convs, bns, xyz, new_xyz, feat, idx):
             and rowmlp.gathered_ok(convs, bns)):
         N = xyz.shape[1]
         w0 = convs[0].weight.view(convs[0].out_channels, 3 + cf)
-        u = rowmlp.point_linear(feat.reshape(B * N, cf), w0[:, 3:])
-        return rowmlp.gathered_mlp(convs, bns, u, None, idx, pool=ns, wx=w0[:, :3], xyz=xyz, ctr=new_xyz)
+        wx, wf = rowmlp.split_cols(w0, 3)
+        u = rowmlp.point_linear(feat.reshape(B * N, cf), wf)
+        return rowmlp.gathered_mlp(convs, bns, u, None, idx, pool=ns, wx=wx, xyz=xyz, ctr=new_xyz)
     rows, perm = rowmlp.group_rows(xyz, new_xyz, feat, idx)
     return rowmlp.mlp_rows(convs, bns, rows, pool=ns, perm=perm)
 

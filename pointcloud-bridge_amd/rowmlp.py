@@ -413,6 +413,32 @@ class _PointLinear(torch.autograd.Function):
         return dx, dw
 
 
+class _SplitCols(torch.autograd.Function):
+    """w[:, :d] and w[:, d:] as two contiguous tensors.  Backward is ONE concatenation: a pair of plain
+    slices costs a zero fill, a copy and an accumulation per piece in the autograd engine (six launches
+    for a weight the GEMMs read in two parts)."""
+
+    @staticmethod
+    def forward(ctx, w, d):
+        ctx.d, ctx.shape = d, w.shape
+        return w[:, :d].contiguous(), w[:, d:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        d, (c, k) = ctx.d, ctx.shape
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = ref.new_zeros(c, d)
+        if gb is None:
+            gb = ref.new_zeros(c, k - d)
+        return torch.cat([ga, gb], dim=1), None
+
+
+def split_cols(w, d):
+    """(w[:, :d], w[:, d:]) of a 2-D weight, contiguous, with a single-launch backward (see _SplitCols)."""
+    return _SplitCols.apply(w, int(d))
+
+
 def point_linear(x, w):
     """x [n, K] @ w[C, K]^T -> fp32 [n, C] with bf16 operands (K, C multiples of 8); see _PointLinear."""
     return _PointLinear.apply(x.to(torch.bfloat16).contiguous(), w.contiguous())
@@ -956,6 +982,49 @@ def scene_concat(a_rows, g, B, N):
     if a_rows.shape[1] % m.q or g.shape[1] % m.q:
         return torch.cat([a_rows.view(B, N, -1), g.view(B, 1, -1).expand(-1, N, -1).to(a_rows.dtype)], dim=2).view(B * N, -1)
     return _SceneConcat.apply(a_rows.to(m.dtype).contiguous(), g.to(m.dtype).contiguous(), B, N, m)
+
+
+class _RepeatConcat(torch.autograd.Function):
+    """out [rows, sum C_l] = levels concatenated along channels, level l given as [rows / r_l, C_l] rows and
+    repeated r_l times (csrc/scenepool.hip: one pass forward, one pass backward with the sums over the repeats)."""
+
+    @staticmethod
+    def forward(ctx, reps, m, *levels):
+        dev = levels[0].device
+        rows = levels[0].shape[0] * reps[0]
+        widths = [int(o.shape[1]) for o in levels]
+        n = len(levels)
+        out = torch.empty(rows, sum(widths), dtype=m.dtype, device=dev)
+        src = (ctypes.c_void_p * n)(*[o.data_ptr() for o in levels])
+        rep = (ctypes.c_int * n)(*reps)
+        wid = (ctypes.c_int * n)(*widths)
+        with on_device(dev):
+            _launch("pcb_repeat_concat_" + m.sfx, 2 * out.numel() * (16 // m.q), n, src, rep, wid, rows, out.data_ptr())
+        ctx.cfg = (reps, widths, m, rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        reps, widths, m, rows = ctx.cfg
+        dev = g.device
+        n = len(widths)
+        g = g.to(m.dtype).contiguous()
+        grads = [torch.empty(rows // reps[l], widths[l], dtype=m.dtype, device=dev) if ctx.needs_input_grad[2 + l] else None
+                 for l in range(n)]
+        dst = (ctypes.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in grads])
+        rep = (ctypes.c_int * n)(*reps)
+        wid = (ctypes.c_int * n)(*widths)
+        with on_device(dev):
+            _launch("pcb_repeat_concat_bwd_" + m.sfx, g.numel() * (16 // m.q), n, g.data_ptr(), rep, wid, rows, dst)
+        return (None, None, *grads)
+
+
+def repeat_concat(levels, reps):
+    """torch.cat([level_l repeated reps[l] times along rows], dim=1) for row tensors [rows / reps[l], C_l] (C_l a
+    multiple of the row mode's column quantum): the nearest-neighbour upsampling + concatenation of
+    MultiScaleFeatureFusion (models/model.py:150-170) without the per-level copies."""
+    m = mode()
+    return _RepeatConcat.apply(tuple(int(r) for r in reps), m, *[o.to(m.dtype).contiguous() for o in levels])
 
 
 def bn_act_rows(bn, x, act=ACT_NONE):

@@ -338,3 +338,50 @@ def test_bench_two_ranks_strong_scaling_equal_the_one_rank_run(tmp_path):
     d = (a["flat"] - b["flat"]).abs()
     print("params: mean |d|", float(d.mean()), "max |d|", float(d.max()))
     assert float(d.mean()) < 1e-3 and float(d.max()) < 6.1e-3   # 3 steps x lr (1e-3) x 2 at most for a sign flip
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_repeat_concat_equals_expand_cat(precision):
+    """rowmlp.repeat_concat (MultiScaleFeatureFusion's nearest upsampling + cat, models/model.py:150-170) against
+    expand + torch.cat: forward bit-exact; backward = the block of the gradient summed over the repeats in fp32
+    (bf16 rows: within one rounding of the fp32 sum)."""
+    from pointcloud_bridge_amd import rowmlp
+    rowmlp.set_precision(precision)
+    try:
+        m = rowmlp.mode()
+        torch.manual_seed(5)
+        B, n = 3, 64
+        reps, widths = [16, 4, 1], [16, 24, 8]
+        levels = [torch.randn(B * n // r, c, device="cuda").to(m.dtype).requires_grad_(True) for r, c in zip(reps, widths)]
+        out = rowmlp.repeat_concat(levels, reps)
+        ref_levels = [t.detach().float().requires_grad_(True) for t in levels]
+        ref = torch.cat([t.view(B * n // r, 1, c).expand(B * n // r, r, c).reshape(B * n, c)
+                         for t, r, c in zip(ref_levels, reps, widths)], dim=1)
+        assert out.shape == ref.shape and torch.equal(out.float(), ref)
+        g = torch.randn_like(ref).to(m.dtype)
+        out.backward(g)
+        ref.backward(g.float())
+        tol = 1e-6 if precision == "fp32" else 2.0 ** -8
+        for t, r in zip(levels, ref_levels):
+            assert t.grad.shape == r.grad.shape
+            err = (t.grad.float() - r.grad).abs().max() / r.grad.abs().max()
+            assert err < tol, err
+    finally:
+        rowmlp.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_split_cols_backward_is_the_concatenation():
+    from pointcloud_bridge_amd import rowmlp
+    w = torch.randn(12, 19, device="cuda", requires_grad=True)
+    a, b = rowmlp.split_cols(w, 3)
+    assert a.is_contiguous() and b.is_contiguous()
+    assert torch.equal(a, w[:, :3]) and torch.equal(b, w[:, 3:])
+    (a.sum() * 2 + (b * b).sum()).backward()
+    ref = torch.cat([torch.full((12, 3), 2.0, device="cuda"), 2 * w.detach()[:, 3:]], dim=1)
+    assert torch.equal(w.grad, ref)
+    w.grad = None
+    a, b = rowmlp.split_cols(w, 3)
+    b.sum().backward()   # one piece unused: its block of the gradient is zero
+    assert torch.equal(w.grad[:, :3], torch.zeros(12, 3, device="cuda")) and torch.equal(w.grad[:, 3:], torch.ones(12, 16, device="cuda"))

@@ -1,36 +1,49 @@
-"""Scratch: GPU time of torch-level ops (by name and input shapes) in one PN2-MSG training step."""
-import os, sys, torch
+"""GPU time of the torch-level (ATen) ops of one bench training step, by op name and input shapes, with the
+autograd node that issued them in the backward pass.  Library kernels are skipped: what is listed here is the
+glue a fused kernel or a layout change could remove.
+
+    python tools/op_time.py [model]
+"""
+import argparse
+import collections
+import os
+import sys
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-from pointcloud_bridge_amd import rowmlp, parallel
-rowmlp.set_precision("bf16")
-dev = torch.device("cuda")
-torch.manual_seed(42)
-name = sys.argv[1] if len(sys.argv) > 1 else "pn2_msg"
-model, cdim = bench.build_model(name)
-model = model.to(dev).train()
-B, N = (8, 8192) if name == "dgcnn" else (16, 16384)
-xyz, colors, labels = bench.synthetic_batch(B, N, 1000, dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
-bucket = parallel.FlatGradAllReduce(model.parameters())
-def step():
-    bucket.zero()
-    loss = bench.loss_fn(model(xyz, colors), labels, cdim)
-    loss.backward()
-    opt.step()
-for _ in range(3):
-    step()
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("model", nargs="?", default="pn2_msg")
+a = ap.parse_args()
+args = argparse.Namespace(no_dropout=False, no_prefetch=False, dump=False)
+dev = torch.device("cuda", 0)
+B, N = (8, 8192) if a.model in ("dgcnn", "bridgeseg") else (16, 16384)
+run = bench.Run(args, a.model, "bf16", B, N, 0, 1, dev)
+for _ in range(4):
+    run.train_step()
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    step()
+    run.train_step()
     torch.cuda.synchronize()
-rows = []
-for e in prof.key_averages(group_by_input_shape=True):
+events = sorted((e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU), key=lambda e: e.time_range.start)
+nodes = [e for e in events if e.name.startswith("autograd::engine::evaluate_function") or e.name.endswith("Backward")]
+rows = collections.defaultdict(lambda: [0.0, 0])
+for e in events:
     t = getattr(e, "self_device_time_total", 0)
-    if t > 0 and not e.key.startswith("void ") and "anonymous namespace" not in e.key and not e.key.startswith("Cijk"):
-        rows.append((t, e.count, e.key, str(e.input_shapes)[:110]))
-tot = sum(r[0] for r in rows)
-print(f"ops with GPU time: {tot/1e3:.2f} ms")
-for t, n, k, sh in sorted(rows, reverse=True)[:60]:
-    print(f"{t:9.1f} us {n:4d}x  {k:34s} {sh}")
+    if t <= 0 or not e.name.startswith("aten::"):
+        continue
+    owner = ""
+    for n in nodes:
+        if n.time_range.start <= e.time_range.start and e.time_range.end <= n.time_range.end and n.thread == e.thread:
+            owner = n.name.replace("autograd::engine::evaluate_function: ", "")
+    key = (e.name, str(e.input_shapes)[:90], owner[:40])
+    rows[key][0] += t
+    rows[key][1] += 1
+tot = sum(v[0] for v in rows.values())
+print(f"ATen ops with GPU time: {tot / 1e3:.2f} ms in {sum(v[1] for v in rows.values())} calls")
+for (name, shapes, owner), (t, n) in sorted(rows.items(), key=lambda kv: -kv[1][0])[:70]:
+    print(f"{t:8.1f} us {n:3d}x {name:28s} {owner:40s} {shapes}")

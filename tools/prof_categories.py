@@ -1,6 +1,6 @@
 """Kernel time per step by family from a `rocprofv3 --kernel-trace --stats` run: prof_categories.py <dir> <steps>."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv") + glob.glob(sys.argv[1] + "/*_kernel_stats.csv"))[0]
 steps = int(sys.argv[2])
 FAMILIES = (("gemm_nt", "gemm_nt"), ("gemm_tn", "gemm_tn"), ("fps_", "fps (side stream)"), ("knn_", "knn"), ("reduce_slabs", "reduce_slabs"),
             ("bn_finalize", "bn_finalize"), ("bn_bwd_finalize", "bn_bwd_finalize"), ("prep_", "prep_weights / prep_linear_bias"),
