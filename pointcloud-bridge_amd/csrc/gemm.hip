@@ -471,7 +471,6 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
 // What was tried and is NOT here: a second register set of staged operands (spills at any
 // occupancy that keeps 16 waves), 64-row tiles at 3 or 4 workgroups per CU (slower: twice the
 // weight traffic from L2).
-constexpr int N8_THREADS = 512;
 constexpr int N8_MAXK = 512;  // columns of constants held in LDS; longer rows use gemm_nt_kernel
 
 template <int PRO>
