@@ -14,7 +14,7 @@ from .. import rowmlp
 from .attention_modules import (BridgeStructureEncoding, ColorFeatureExtraction, CompositeFeatureFusion,
                                 GeometricFeatureExtraction)
 from .pointnet2_utils import (EnhancedFeaturePropagation, FeaturePropagation, MultiScaleSetAbstraction,
-                              SetAbstraction, _channels_last, _seq_rows, prefetch_sampling)
+                              SetAbstraction, _channels_last, _seq_rows, prefetch_sampling, run_branches)
 
 
 class _SamplingPrefetchMixin:
@@ -109,9 +109,10 @@ class MultiScaleFeatureFusion(nn.Module):
         """[B,C_i,S_i] levels -> [B, N, 3*out] channels-last rows (nearest resampling along the
         point axis, exactly F.interpolate(feat, size=N) of models/model.py:164)."""
         n = features_list[2].shape[2]
-        outs, reps = [], []
         B = features_list[0].shape[0]
-        for f, conv in zip(features_list, self.convs):
+
+        def level(f, conv):
+            """(rows of this level after its layer, how often each is repeated)"""
             _, _, S = f.shape
             rows = _channels_last(f)
             r = n // S
@@ -124,16 +125,28 @@ class MultiScaleFeatureFusion(nn.Module):
                     # on the S coarse rows (r times less GEMM work, forward and backward) and
                     # repeat its output.  Only the sample count of the unbiased running variance
                     # differs, which stat_repeat restores.
-                    outs.append(rowmlp.conv_bn_act(conv[0], conv[1], rows.reshape(B * S, -1), rowmlp.ACT_RELU, stat_repeat=r))
-                    reps.append(r)  # repeated on write below
-                    continue
+                    return rowmlp.conv_bn_act(conv[0], conv[1], rows.reshape(B * S, -1), rowmlp.ACT_RELU, stat_repeat=r), r
                 rows = rows.unsqueeze(2).expand(B, S, r, rows.shape[2]).reshape(B, n, rows.shape[2])
             elif S != n:
                 ramp = torch.arange(S, dtype=torch.float32, device=f.device).view(1, 1, S)
                 src = F.interpolate(ramp, size=n).view(n).long()  # the very index map F.interpolate uses
                 rows = rows.index_select(1, src)
-            outs.append(_seq_rows(conv, rows.reshape(B * n, -1)))
-            reps.append(1)
+            return _seq_rows(conv, rows.reshape(B * n, -1)), 1
+
+        # the levels are independent: the full-resolution one on the caller's stream, the coarse ones beside it
+        order = sorted(range(len(features_list)), key=lambda i: -features_list[i].shape[2])
+        reps_of = {}
+
+        def run(i):
+            o, r = level(features_list[i], self.convs[i])
+            reps_of[i] = r
+            return o
+
+        res = run_branches(features_list[0].device, [(lambda i=i: run(i)) for i in order], inputs=tuple(features_list))
+        outs = [None] * len(order)
+        for i, o in zip(order, res):
+            outs[i] = o
+        reps = [reps_of[i] for i in range(len(order))]
         q = rowmlp.mode().q
         if all(r == 1 for r in reps) or any(o.shape[1] % q for o in outs) or len(outs) > 4:
             return torch.cat([o.view(B, n // r, 1, -1).expand(B, n // r, r, o.shape[1]).reshape(B, n, -1)

@@ -14,13 +14,14 @@ transposed views of channels-last storage.
 
 GPU only: CPU tensors raise (there is no fallback path).
 """
+import os
 import weakref
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops, rowmlp
+from .. import ops, parallel, rowmlp
 
 
 # ---------------------------------------------------------------------------------------------
@@ -410,6 +411,53 @@ class SetAbstraction(nn.Module):
         return new_xyz, x.view(B, self.npoint, -1).transpose(1, 2)
 
 
+# Independent sub-chains of a module (the scales of an MSG set abstraction, the boundary term of a decoder
+# stage, the levels of the feature fusion) are chains of small DEPENDENT launches, and a small launch
+# between two large ones costs ~6 us of an otherwise idle chip (tools/micro/launch_floor.hip).  Run on
+# streams of their own, one chain's gaps are filled by another chain's kernels; autograd replays every
+# backward node on the stream of its forward, so the backward pass overlaps the same way.
+# PCB_BRANCH_STREAMS=0 turns it off (every chain on the caller's stream).
+_branch_streams_on = os.environ.get("PCB_BRANCH_STREAMS", "1") == "1"
+_branch_pool = []
+
+
+def set_branch_streams(flag):
+    global _branch_streams_on
+    _branch_streams_on = bool(flag)
+
+
+def _branches(device, n):
+    while len(_branch_pool) < n:
+        _branch_pool.append(torch.cuda.Stream(device=device))
+        parallel.register_compute_stream(_branch_pool[-1])  # gradient buckets packed during backward wait for it
+    return _branch_pool[:n]
+
+
+def run_branches(device, fns, inputs=()):
+    """[fn() for fn in fns], fn i > 0 on branch stream i - 1 (forked from and joined to the current stream).
+    Every fn returns a tensor; the results are safe to use on the current stream afterwards.
+    inputs: the tensors of the CURRENT stream the branches read (and may save for backward).  In the backward
+    pass a branch reads them on its own stream and drops them with no join behind it, so they are marked as
+    used by the branch streams -- their blocks are not handed out again before that work is done."""
+    if not (_branch_streams_on and device.type == "cuda" and len(fns) > 1) or torch.cuda.is_current_stream_capturing():
+        return [fn() for fn in fns]
+    main = torch.cuda.current_stream()
+    streams = [main] + _branches(device, len(fns) - 1)
+    for st in streams[1:]:
+        st.wait_stream(main)
+        for t in inputs:
+            if t is not None and t.is_cuda:
+                t.record_stream(st)
+    outs = []
+    for st, fn in zip(streams, fns):
+        with torch.cuda.stream(st):
+            outs.append(fn())
+    for st, o in zip(streams[1:], outs[1:]):
+        main.wait_stream(st)
+        o.record_stream(main)
+    return outs
+
+
 class MultiScaleSetAbstraction(nn.Module):
     """Multi-scale grouping set abstraction (reference :302-360).  `in_channel` already counts the
     3 centred coordinates (models/model.py:69,75-76)."""
@@ -436,10 +484,10 @@ class MultiScaleSetAbstraction(nn.Module):
         _, new_xyz = _sample(xyz, self.npoint)  # one FPS for all scales (:335)
         idx_list = _ball_indices(self.radius_list, self.nsample_list, xyz, new_xyz)
         B = xyz.shape[0]
-        outs = []
-        for i, idx in enumerate(idx_list):
-            x = _grouped_mlp(self.conv_blocks[i], self.bn_blocks[i], xyz, new_xyz, feat, idx)
-            outs.append(x.view(B, self.npoint, -1))
+        # the scales are independent chains: each on its own stream (run_branches)
+        outs = run_branches(xyz.device, [
+            (lambda i=i, idx=idx: _grouped_mlp(self.conv_blocks[i], self.bn_blocks[i], xyz, new_xyz, feat, idx)
+             .view(B, self.npoint, -1)) for i, idx in enumerate(idx_list)], inputs=(xyz, new_xyz, feat, *idx_list))
         return new_xyz, torch.cat(outs, dim=2).transpose(1, 2)
 
 
@@ -522,12 +570,17 @@ class EnhancedFeaturePropagation(nn.Module):
         B, N, _ = xyz1.shape
         x, perm = _propagate_rows(xyz1, xyz2, points1, points2, 4)
         att = self.attention                                        # :279-280
-        a = rowmlp.conv_bn_act(att[0], att[1], x, rowmlp.ACT_RELU, perm=perm)
-        x = rowmlp.gate_rows(x, rowmlp.conv_rows(att[3], a, out_gap=-perm))
-        edge = _seq_rows(self.boundary_aware, xyz1.reshape(B * N, 3))  # :283
-        identity = x
-        x = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, x, perm=perm)
-        if self.skip_connection:
-            x = x + rowmlp.ungap_rows(identity, perm)               # :292-293
-        x = x + edge                                                # :296
+
+        def trunk():
+            a = rowmlp.conv_bn_act(att[0], att[1], x, rowmlp.ACT_RELU, perm=perm)
+            g = rowmlp.gate_rows(x, rowmlp.conv_rows(att[3], a, out_gap=-perm))
+            y = rowmlp.mlp_rows(self.mlp_convs, self.mlp_bns, g, perm=perm)
+            if self.skip_connection:
+                y = y + rowmlp.ungap_rows(g, perm)                  # :292-293
+            return y
+
+        # the boundary term depends on the coordinates only: its own stream beside the trunk
+        y, edge = run_branches(xyz1.device, [trunk, lambda: _seq_rows(self.boundary_aware, xyz1.reshape(B * N, 3))],
+                               inputs=(xyz1,))                       # :283
+        x = y + edge                                                # :296
         return x.view(B, N, -1).transpose(1, 2)

@@ -105,6 +105,18 @@ class FlatGradAllReduce:
                 p.grad = v
 
 
+# Streams besides the caller's on which backward nodes may run: a model that runs independent branches on
+# streams of its own (models/pointnet2_utils.run_branches) registers them here.  A bucket is packed by the hook
+# of whichever parameter's gradient lands last, on THAT node's stream; the other gradients of the bucket may
+# have been produced on the other streams, so the packing waits for all of them first.
+compute_streams = []
+
+
+def register_compute_stream(stream):
+    if all(stream != s for s in compute_streams):
+        compute_streams.append(stream)
+
+
 class OverlappedGradAllReduce:
     """The flat gradient all-reduce, started bucket by bucket WHILE the backward pass is still running.
 
@@ -182,6 +194,14 @@ class OverlappedGradAllReduce:
         gradient counts as zero), then its slice starts travelling."""
         lo, hi, _ = self.ranges[b]
         members = [i for i, k in enumerate(self.bucket_of) if k == b]
+        if self.flat.is_cuda and compute_streams:
+            cur = torch.cuda.current_stream()
+            for s in compute_streams:
+                if s != cur:
+                    cur.wait_stream(s)
+            for i in members:
+                if self.params[i].grad is not None:
+                    self.params[i].grad.record_stream(cur)  # allocated on its own node's stream, read here
         torch.cat([(self.params[i].grad if self.params[i].grad is not None else torch.zeros_like(self.params[i])).reshape(-1)
                    for i in members], out=self.flat[lo:hi])
         for i in members:

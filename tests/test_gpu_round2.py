@@ -385,3 +385,58 @@ def test_split_cols_backward_is_the_concatenation():
     a, b = rowmlp.split_cols(w, 3)
     b.sum().backward()   # one piece unused: its block of the gradient is zero
     assert torch.equal(w.grad[:, :3], torch.zeros(12, 3, device="cuda")) and torch.equal(w.grad[:, 3:], torch.ones(12, 16, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_branch_streams_change_nothing():
+    """The independent sub-chains of PN2-MSG (MSG scales, decoder boundary terms, fusion levels) on streams of
+    their own (pointnet2_utils.run_branches) against the same step on one stream: the same kernels in the same
+    per-chain order.  The step itself is not bit-reproducible (the gathered set abstraction scatters du with fp32
+    atomics, and one changed bf16 rounding moves a ReLU mask), so the yardstick is the spread between two
+    single-stream runs: the branch-stream runs must stay within a few times that.  A missing synchronisation
+    (forward join, saved inputs released under a running branch, gradient buckets packed during backward) shows
+    as errors of the gradients' own size -- test_bridgeseg_logit_parity caught one at 30 %."""
+    import bench
+    from pointcloud_bridge_amd import parallel, rowmlp
+    from pointcloud_bridge_amd.models import pointnet2_utils as pu
+    rowmlp.set_precision("bf16")
+    try:
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(42)
+        model, cdim = bench.build_model("pn2_msg")
+        model = model.to(dev).train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        xyz, colors, labels = bench.synthetic_batch(4, 4096, 123, dev)
+        bucket = parallel.OverlappedGradAllReduce.by_children(model)
+
+        def step(flag):
+            pu.set_branch_streams(flag)
+            model.load_state_dict(state)
+            torch.manual_seed(7)  # FPS start indices
+            bucket.zero()
+            loss = bench.loss_fn(model(xyz, colors), labels, cdim)
+            loss.backward()
+            flat = bucket.finish().clone()
+            junk = [torch.randn(1 << 20, device=dev) for _ in range(4)]  # allocator churn between runs
+            del junk
+            return float(loss), flat
+
+        ref_loss, ref_flat = step(False)
+        loss2, flat2 = step(False)
+        scale = float(ref_flat.abs().max())
+        spread = float((flat2 - ref_flat).abs().max())
+        l2_spread = float((flat2 - ref_flat).norm() / ref_flat.norm())
+        assert abs(loss2 - ref_loss) < 1e-5 * abs(ref_loss)
+        for _ in range(3):
+            loss, flat = step(True)
+            assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss)
+            err = float((flat - ref_flat).abs().max())
+            l2 = float((flat - ref_flat).norm() / ref_flat.norm())
+            assert err <= 4 * spread + 1e-6 * scale, (err, spread, scale)
+            assert l2 <= 4 * l2_spread + 1e-6, (l2, l2_spread)
+    finally:
+        pu.set_branch_streams(True)
+        rowmlp.set_precision("fp32")
