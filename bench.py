@@ -298,6 +298,32 @@ class Run:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def isolated_launches(self, steps=2, warmup=3):
+        """HIP-event durations of the roofline kernel family with every chain of the model on ONE stream.
+        In the timed region the independent chains of a module run on branch streams
+        (pointnet2_utils.run_branches) and two GEMMs that share the chip each take longer than alone: a
+        launch's own duration -- what a roofline fraction is about -- needs steps without that.  Run AFTER the
+        timed region and not inside it: switching moves the step's tensors to another stream's allocator pool
+        (a burst of hipMalloc calls), which would cost the timed steps around it more than a millisecond each."""
+        from pointcloud_bridge_amd import ops
+        from pointcloud_bridge_amd.models import pointnet2_utils as pu
+        if self.mode != "train" or self.use_graph or not pu.branch_streams_enabled():
+            return None
+        pu.set_branch_streams(False)
+        try:
+            for _ in range(warmup):
+                self.train_step()
+            self.fence()
+            ops.kernel_timer_start()
+            for _ in range(steps):
+                ops.kernel_timer_enable(True)
+                self.train_step()
+            self.fence()
+            launches, kernel_ms, nt_bytes = ops.kernel_timer_stop()
+        finally:
+            pu.set_branch_streams(True)
+        return {"nt_launches": launches, "nt_ms": kernel_ms, "nt_bytes": nt_bytes}
+
     def timed(self, steps, warmup, roofline=True):
         from pointcloud_bridge_amd import ops
         step = (self.graph_step if self.use_graph else self.train_step) if self.mode == "train" else self.infer_step
@@ -416,6 +442,8 @@ def main():
     run = Run(args, args.model, args.precision, B, N, rank, world, device, args.mode, args.data, args.graph, args.loss,
               args.sync_bn, strong)
     res = run.timed(args.steps, args.warmup)
+    # (every rank: the steps contain the gradient all-reduce)
+    iso = run.isolated_launches() if not (os.environ.get("PCB_BENCH_NO_ROOFLINE") or args.dump) else None
     if args.dump and rank == 0:
         torch.save({"losses": res["losses"], "flat": run.opt.flat.detach().cpu(),
                     "first_grad": getattr(run, "first_grad", torch.zeros(0)).cpu()}, args.dump)
@@ -438,6 +466,13 @@ def main():
                 with open(pmc) as f:
                     traffic = json.load(f)["traffic_bytes_per_launch"]
                 break
+        concurrent = None
+        if iso and iso["nt_launches"]:
+            # the timed region's figures (GEMMs of concurrent chains share the chip) go along for the record
+            c_n = max(res["nt_launches"], 1)
+            concurrent = {"launches": res["nt_launches"], "avg_launch_us": res["nt_ms"] / c_n * 1e3,
+                          "achieved": (res["nt_bytes"] / c_n) / (res["nt_ms"] / c_n * 1e-3) / 1e9 if res["nt_launches"] else 0.0}
+            res = dict(res, **iso)
         launches = res["nt_launches"]
         alg_bytes = res["nt_bytes"] / max(launches, 1)   # per launch
         avg_s = res["nt_ms"] / max(launches, 1) * 1e-3
@@ -470,6 +505,12 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": launches, "avg_launch_us": avg_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "sampling": ("HIP events around every launch of the family in 2 steps run right after the timed "
+                                      "region with all chains of the model on one stream (a launch's own duration); "
+                                      "`timed_region` holds the same measurement on every 10th timed step, where GEMMs "
+                                      "of concurrent chains share the chip") if concurrent else
+                                     "HIP events around every launch of the family on every 10th timed step",
+                         "timed_region": concurrent,
                          # algorithmic bytes of ALL kernel families of the library over the step time
                          # (ATen glue not counted), with the sampling chain's time as a separate latency term
                          "whole_step": {"algorithmic_bytes_per_step": res["lib_bytes_per_step"], "achieved": whole,

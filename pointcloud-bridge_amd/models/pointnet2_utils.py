@@ -426,6 +426,10 @@ def set_branch_streams(flag):
     _branch_streams_on = bool(flag)
 
 
+def branch_streams_enabled():
+    return _branch_streams_on
+
+
 def _branches(device, n):
     while len(_branch_pool) < n:
         _branch_pool.append(torch.cuda.Stream(device=device))
@@ -439,7 +443,10 @@ def run_branches(device, fns, inputs=()):
     inputs: the tensors of the CURRENT stream the branches read (and may save for backward).  In the backward
     pass a branch reads them on its own stream and drops them with no join behind it, so they are marked as
     used by the branch streams -- their blocks are not handed out again before that work is done."""
-    if not (_branch_streams_on and device.type == "cuda" and len(fns) > 1) or torch.cuda.is_current_stream_capturing():
+    # (a no-grad pass is host-bound -- 3 ms of enqueueing for 2.7 ms of kernels at B=16 x N=16384 -- and the
+    # fork/join calls only add to that: branches are for training steps)
+    if (not (_branch_streams_on and device.type == "cuda" and len(fns) > 1 and torch.is_grad_enabled())
+            or torch.cuda.is_current_stream_capturing()):
         return [fn() for fn in fns]
     main = torch.cuda.current_stream()
     streams = [main] + _branches(device, len(fns) - 1)
