@@ -10,7 +10,7 @@ agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for r in csv.DictReader(open(f)):
     if r["Counter_Name"] != "SQ_VALU_MFMA_BUSY_CYCLES":
         continue
-    m = re.search(r"(gemm_nt_ares_kernel|gemm_nt_kernel|gemm_tn_kernel|knn_mfma_kernel)<[^>]*>", r["Kernel_Name"])
+    m = re.search(r"(gemm_nt_ares_kernel|gemm_nt8_kernel|gemm_nt_kernel|gemm_tn_kernel|knn_mfma_kernel)<[^>]*>", r["Kernel_Name"])
     if not m:
         continue
     a = agg[m.group(0)]
