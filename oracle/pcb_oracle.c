@@ -183,11 +183,44 @@ void orc_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int
  * transposed to [B,N,D] (DGCNN.py:60).  pd(i,j) = (|xi|^2 + (-2*<xi,xj>)) + |xj|^2 (:63-65);
  * the k largest of -pd, i.e. the k smallest pd, best first.  Ties: lowest index first
  * (torch.topk leaves tie order unspecified; parity tests compare tie-tolerantly).
- * <xi,xj> is an fmaf chain in channel order, |x|^2 a plain left-to-right sum: for D = 3
- * this is what the reference's sgemm yields; for larger D the reference's blocked sgemm
- * may differ in the last bits, which the tests account for.
- * Also returns the distances so near-tie mismatches can be judged.
+ * <xi,xj> is an fmaf chain in channel order: bit for bit what the reference's sgemm (MKL 2024.2,
+ * AVX-512) yields for K = 3 and K = 64 (tools/sgemm_order.py: 100 % of the inner products; 2-16 split
+ * accumulators, reversed or unfused chains agree on 14-31 % only).
+ * |x|^2 = torch.sum(x**2, dim=2) over the contiguous channel axis is ATen's vectorised reduction: for
+ * D % 32 == 0 four 8-lane accumulators take the 8-channel chunks in turn (chunk t goes to accumulator
+ * t % 4), the accumulators are added left to right, then the 8 lanes left to right (bit-identical for
+ * D = 32, 64, 128, 256 -- the widths DGCNN's graphs have besides D = 3); other D: plain left-to-right
+ * sum (pinned for D = 3 by the golden vectors, unpinned for the rest).
+ * Also returns the distances so that exact ties can be told from mismatches.
  */
+static float sumsq_aten(const float *p, int D)
+{
+    if (D % 32 != 0) {
+        float s = 0.0f;
+        for (int c = 0; c < D; ++c) {
+            float sq = p[c] * p[c];
+            s = c ? s + sq : sq;
+        }
+        return s;
+    }
+    float acc[4][8];
+    for (int u = 0; u < 4; ++u)
+        for (int l = 0; l < 8; ++l) {
+            float a = p[u * 8 + l] * p[u * 8 + l];
+            for (int c0 = u * 8 + 32; c0 < D; c0 += 32) {
+                float sq = p[c0 + l] * p[c0 + l];
+                a = a + sq;
+            }
+            acc[u][l] = a;
+        }
+    float r = 0.0f;
+    for (int l = 0; l < 8; ++l) {
+        float v = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+        r = l ? r + v : v;
+    }
+    return r;
+}
+
 void orc_knn(const float *x, int B, int N, int D, int k, int64_t *out_i, float *out_d)
 {
 #pragma omp parallel for schedule(static)
@@ -196,14 +229,7 @@ void orc_knn(const float *x, int B, int N, int D, int k, int64_t *out_i, float *
         float *nrm = (float *)malloc(sizeof(float) * (size_t)N);
         float *bd = (float *)malloc(sizeof(float) * (size_t)k);
         int64_t *bi = (int64_t *)malloc(sizeof(int64_t) * (size_t)k);
-        for (int i = 0; i < N; ++i) {
-            float s = 0.0f;
-            for (int c = 0; c < D; ++c) {
-                float sq = xb[(size_t)i * D + c] * xb[(size_t)i * D + c];
-                s = c ? s + sq : sq;
-            }
-            nrm[i] = s;
-        }
+        for (int i = 0; i < N; ++i) nrm[i] = sumsq_aten(xb + (size_t)i * D, D);
         for (int i = 0; i < N; ++i) {
             const float *xi = xb + (size_t)i * D;
             int have = 0;

@@ -21,8 +21,8 @@
 //   lanes n and n+32 merge their lists at the end (ties: lower index first)
 //   The candidate stages are double-buffered: the next stage's rows are in flight (registers) while
 //   the MFMAs of the current one run, one barrier per stage.  |x_j|^2 comes from a small pre-pass
-//   (knn_norms_kernel: one lane per point, the same left-to-right sum the reference's
-//   torch.sum(x**2) chain is pinned to) instead of 64 lanes recomputing it per stage.
+//   (knn_norms_kernel: one lane per point, in the summation order of the reference's torch.sum(x**2))
+//   instead of 64 lanes recomputing it per stage.
 #include "pcb_common.h"
 
 namespace {
@@ -74,7 +74,10 @@ __device__ __forceinline__ void insert_sorted_by_index(float (&bd)[K], int (&bi)
     bi[0] = hi ? cand : bi[0];
 }
 
-// |x|^2 of every point: left-to-right sum of squares, multiply and add rounded separately.
+// |x|^2 of every point in the order of the reference's torch.sum(x**2, dim=2) (models/DGCNN.py:64), multiply and
+// add rounded separately.  ATen's vectorised reduction over a contiguous axis (tools/sgemm_order.py, bit-identical
+// for D = 32..256): D % 32 == 0 -> four 8-lane accumulators take the 8-channel chunks in turn, accumulators added
+// left to right, then the lanes left to right; other D (D = 3: the coordinates) -> one left-to-right chain.
 __global__ __launch_bounds__(kThreads) void knn_norms_kernel(const float *__restrict__ x, long rows, int D,
                                                               float *__restrict__ norms)
 {
@@ -82,9 +85,21 @@ __global__ __launch_bounds__(kThreads) void knn_norms_kernel(const float *__rest
     if (r >= rows) return;
     const float *__restrict__ p = x + r * D;
     float s = 0.0f;
-    for (int c = 0; c < D; ++c) {
-        const float v = p[c];
-        s = c ? __fadd_rn(s, __fmul_rn(v, v)) : __fmul_rn(v, v);
+    if (D % 32 == 0) {
+        for (int l = 0; l < 8; ++l) {
+            float v = 0.0f;
+            for (int u = 0; u < 4; ++u) {
+                float a = __fmul_rn(p[u * 8 + l], p[u * 8 + l]);
+                for (int c0 = u * 8 + 32; c0 < D; c0 += 32) a = __fadd_rn(a, __fmul_rn(p[c0 + l], p[c0 + l]));
+                v = u ? __fadd_rn(v, a) : a;
+            }
+            s = l ? __fadd_rn(s, v) : v;
+        }
+    } else {
+        for (int c = 0; c < D; ++c) {
+            const float v = p[c];
+            s = c ? __fadd_rn(s, __fmul_rn(v, v)) : __fmul_rn(v, v);
+        }
     }
     norms[r] = s;
 }

@@ -80,14 +80,19 @@ def test_knn_feature_space_d64():
     x = np.ascontiguousarray(g["knn64_x"].transpose(0, 2, 1))
     idx, d = orc.knn(x, 20, return_dist=True)
     ref = g["knn64_idx"]
-    x64 = x.astype(np.float64)
-
-    def dist_of(b, i, js):
-        return ((x64[b, js] - x64[b, i]) ** 2).sum(-1)
-
-    # the reference's blocked sgemm rounds differently at D = 64: allow swaps of near-equal distances
-    assert knn_tie_tolerant_mismatch(idx, ref, dist_of, rtol=1e-5, atol=1e-4) == 0
-    assert (idx != ref).mean() < 1e-3
+    # The oracle follows the reference's two reductions bit for bit (tools/sgemm_order.py: MKL's K = 64 inner
+    # product is ONE fma chain in channel order, torch.sum(x**2, dim=2) is ATen's 4 x 8-lane vectorised sum), so
+    # the fp32 distance matrix is the reference's: the lists may differ only by a permutation of EXACTLY equal
+    # fp32 distances (torch.topk leaves their order open).  The fp32 distances of any candidate come from the
+    # oracle's full ranking (k = N).
+    B, N, _ = x.shape
+    full_i, full_d = orc.knn(x, N, return_dist=True)
+    dmap = np.empty((B, N, N), np.float32)
+    for b in range(B):
+        for i in range(N):
+            dmap[b, i, full_i[b, i]] = full_d[b, i]
+    assert knn_tie_tolerant_mismatch(idx, ref, lambda b, i, js: dmap[b, i, js]) == 0
+    assert (idx != ref).mean() < 1e-4   # measured: 0 of 15360 entries
 
 
 def test_edge_features():
