@@ -11,7 +11,7 @@ xyz = torch.rand(int(os.environ.get("FPS_B", "16")), 16384, 3, device="cuda"); s
 side = torch.cuda.Stream()
 def gemm():
     L.pcb_gemm_nt_bf16(2, x.data_ptr(), y.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), 0, 0, 1, 1,
-                       w.data_ptr(), R, N, K, out.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+                       w.data_ptr(), R, N, K, out.data_ptr(), 0, 0, torch.cuda.current_stream().cuda_stream)
 def run(with_fps):
     torch.cuda.synchronize()
     if with_fps:
