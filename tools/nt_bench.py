@@ -73,7 +73,7 @@ def main():
         v = [torch.rand(K, device=dev) + 0.5 for _ in range(4)]
         rv = [torch.rand(N, device=dev) + 0.5 for _ in range(4)]
         stats = (pro <= 1 and N >= 32) or red
-        nparts = L.pcb_gemm_nt_partials(pro, R, N)
+        nparts = int(os.environ.get("NT_NPARTS", "0")) or L.pcb_gemm_nt_partials(pro, R, N)
         sums = torch.zeros(nparts, 2, N, device=dev)
         dout = torch.randn(R // ns, K, device=dev)
         arg = torch.randint(0, ns, (R // ns, K), device=dev, dtype=torch.uint8)
