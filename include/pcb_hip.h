@@ -588,6 +588,19 @@ int pcb_repeat_concat_bwd_bf16(int n, const void *g, const int *rep, const int *
 int pcb_repeat_concat_bwd_f32(int n, const void *g, const int *rep, const int *width, long rows, void *const *dsrc, void *stream);
 
 /*
+ * Global scaled-dot-product attention, forward -- row f4: F.scaled_dot_product_attention(q, k, v) of
+ * PointAttention.forward (models/PointTransformerV3.py:64-117, the call at :102; inference_ptv3.py:101-105: embed 384,
+ * 2 heads, head_dim 192), every point of a scene attending to every point of it.
+ *   qkv  [B, N, 3, H, D] bf16: the output of the reference's qkv projection as it stands (:96) -- q, k, v of head h of
+ *        token n at offsets 0, H*D, 2*H*D (+ h*D) of the token's 3*H*D values
+ *   out  [B, N, H*D] bf16 = softmax(q k^T * scale) v, heads side by side: the layout after the reference's
+ *        transpose(1, 2).reshape(B, N, C) (:113)
+ * One flash-attention pass (online softmax in fp32, bf16 MFMA products, nothing of size N x N stored).  D in
+ * {64, 128, 192, 256}; scale = D^-0.5 in the reference.  Inference configuration: no backward.
+ */
+int pcb_attention_fwd_bf16(const void *qkv, int B, int N, int H, int D, float scale, void *out, void *stream);
+
+/*
  * A whole stack of L <= PCB_STACK_MAX_LAYERS shared-MLP layers  x -> act(BN(x W^T + b))  [-> max over
  * each `pool` consecutive rows]  enqueued from ONE call -- the loop the reference writes as
  *   for i, conv in enumerate(self.mlp_convs): new_points = F.relu(self.mlp_bns[i](conv(new_points)))

@@ -259,6 +259,29 @@ def three_nn(xyz1, xyz2, k=3):
     return d2, idx
 
 
+def attention(qkv, num_heads, scale=None):
+    """softmax(q k^T * scale) v over all points of a scene, for every head: qkv [B, N, 3*C] -- the output of the
+    reference's qkv projection (models/PointTransformerV3.py:96: [.., 3, H, C/H]) -- -> [B, N, C] bf16, the layout
+    after the reference's transpose + reshape (:113).  Forward only (cfg5 is an inference configuration);
+    head_dim in {64, 128, 192, 256}; scale defaults to head_dim ** -0.5 (:79)."""
+    _need_cuda(qkv)
+    if qkv.dim() != 3 or qkv.shape[2] % (3 * num_heads):
+        raise ValueError(f"qkv must be [B, N, 3*C] with C divisible by num_heads, got {tuple(qkv.shape)}")
+    if qkv.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("pcb_attention_fwd has no backward: call it under torch.no_grad()")
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    D = C // num_heads
+    if D not in (64, 128, 192, 256):
+        raise ValueError(f"head_dim {D} not supported (64, 128, 192, 256)")
+    x = qkv.detach().to(torch.bfloat16).contiguous()
+    out = torch.empty(B, N, C, dtype=torch.bfloat16, device=x.device)
+    with on_device(x.device):
+        _launch("pcb_attention_fwd_bf16", 4 * B * num_heads * N * N * D, x.data_ptr(), B, N, num_heads, D,
+                float(D ** -0.5 if scale is None else scale), out.data_ptr())
+    return out
+
+
 def knn(x_bnd, k):
     """kNN graph on x [B,N,D] (DGCNN.py:49-70 after its transpose at :60) -> [B,N,k] int64."""
     _need_cuda(x_bnd)

@@ -440,3 +440,36 @@ def test_branch_streams_change_nothing():
     finally:
         pu.set_branch_streams(True)
         rowmlp.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_confusion_matrices_on_device_equal_the_per_point_loop():
+    """Row f2: inference.py:226-231 fills the global and the per-file confusion matrices point by point in a
+    Python loop (`for t, p in zip(targets, preds): cm[t, p] += 1`).  train.confusion_matrix /
+    per_scene_confusion on DEVICE tensors (one bincount each) against that loop restated in numpy, and the
+    metrics of inference.py:814-855 against their definition term by term.  (The reference module itself needs
+    laspy / seaborn and cannot be imported: parity with a reference RUN stays unpinned.)"""
+    from pointcloud_bridge_amd import train
+    rng = np.random.default_rng(3)
+    B, N, C = 5, 4096, 5
+    target = rng.integers(0, C, (B, N))
+    pred = np.where(rng.random((B, N)) < 0.7, target, rng.integers(0, C, (B, N)))
+    pred[:, :7] = 4      # a class that is predicted but ...
+    target[target == 3] = 2  # ... one that never occurs as truth
+    per = np.zeros((B, C, C), np.int64)
+    for b in range(B):
+        for t, p in zip(target[b], pred[b]):
+            per[b, t, p] += 1
+    dt, dp = torch.from_numpy(target).cuda(), torch.from_numpy(pred).cuda()
+    got_per = train.per_scene_confusion(dp, dt, C)
+    got = train.confusion_matrix(dp, dt, C)
+    assert got.is_cuda and got_per.is_cuda
+    assert np.array_equal(got_per.cpu().numpy(), per)
+    assert np.array_equal(got.cpu().numpy(), per.sum(0))
+    m = train.metrics_from_confusion(got)
+    cm = per.sum(0).astype(np.float64)
+    diag = np.diag(cm)
+    iou = diag / (cm.sum(1) + cm.sum(0) - diag + 1e-6)
+    assert abs(float(m["miou"]) - iou.mean()) < 1e-12
+    assert abs(float(m["oa"]) - diag.sum() / cm.sum()) < 1e-9
+    assert float(m["iou"][3]) == 0.0   # absent class: IoU 0 (not NaN) and it DOES enter the mean (:826, :846)
