@@ -232,8 +232,11 @@ class Run:
         graph's tensors are fixed)."""
         from pointcloud_bridge_amd.models import pointnet2_utils as pu
         model, bucket, opt = self.model, self.bucket, self.opt
-        xyz, colors, _ = self.batches[0]
-        batch = self.batches[0]
+        # the graph's tensors are fixed: the step's batch is copied into them before every replay, and the NEXT
+        # batch's coordinates into `xyz_next`, from which the captured step computes the next sampling pyramid
+        xyz, colors, labels = (t.clone() for t in self.batches[0])
+        xyz_next = xyz.clone()
+        batch = (xyz, colors, labels)
         static = None
         if hasattr(model, "sa1"):
             static = pu.StaticSampling(xyz, [model.sa1.npoint, model.sa2.npoint, model.sa3.npoint])
@@ -248,7 +251,7 @@ class Run:
             if static is not None:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    static.compute(xyz)          # pyramid of the next step, beside the backward pass
+                    static.compute(xyz_next)     # pyramid of the next step's batch, beside the backward pass
             loss.backward()
             if static is not None:
                 torch.cuda.current_stream().wait_stream(side)
@@ -274,7 +277,14 @@ class Run:
             fwd_bwd()
         grads = [p.grad for p in self.params if p.grad is not None]  # the graph's fixed tensors
 
+        def load_batches():
+            cur, nxt = self._batch(), self._batch(1)
+            xyz.copy_(cur[0]); colors.copy_(cur[1]); labels.copy_(cur[2])
+            xyz_next.copy_(nxt[0])
+            self.i += 1
+
         def graph_step():
+            load_batches()
             if static is not None:
                 static.draw()
             graph.replay()
@@ -285,6 +295,7 @@ class Run:
         def eager_step():
             """The same step launched kernel by kernel (HIP events around the roofline kernel need
             real launches); gradients accumulate into the graph's tensors, zeroed first."""
+            load_batches()
             if static is not None:
                 static.draw()
             torch._foreach_zero_(grads)
@@ -293,7 +304,7 @@ class Run:
             opt.step(bucket.flat)
             return loss_buf
 
-        self.graph_step, self.eager_step = graph_step, eager_step
+        self.graph_step, self.eager_step, self.static = graph_step, eager_step, static
 
     # -- the timed loop ---------------------------------------------------------------------------
     def fence(self):
@@ -311,22 +322,43 @@ class Run:
         (a burst of hipMalloc calls), which would cost the timed steps around it more than a millisecond each."""
         from pointcloud_bridge_amd import ops
         from pointcloud_bridge_amd.models import pointnet2_utils as pu
-        if self.mode != "train" or self.use_graph or not pu.branch_streams_enabled():
+        if self.mode != "train" or not (self.use_graph or pu.branch_streams_enabled()):
             return None
+        step = self.eager_step if self.use_graph else self.train_step
+        branches = pu.branch_streams_enabled()
         pu.set_branch_streams(False)
         try:
             for _ in range(warmup):
-                self.train_step()
+                step()
             self.fence()
             ops.kernel_timer_start()
             for _ in range(steps):
                 ops.kernel_timer_enable(True)
-                self.train_step()
+                step()
             self.fence()
             launches, kernel_ms, nt_bytes = ops.kernel_timer_stop()
+            all_n, _, all_bytes = ops.kernel_timer_read(-1)
         finally:
-            pu.set_branch_streams(True)
-        return {"nt_launches": launches, "nt_ms": kernel_ms, "nt_bytes": nt_bytes}
+            pu.set_branch_streams(branches)
+        return {"nt_launches": launches, "nt_ms": kernel_ms, "nt_bytes": nt_bytes,
+                "lib_launches_per_step": all_n / steps, "lib_bytes_per_step": all_bytes / steps}
+
+    def probe(self, steps=6, warmup=5):
+        """Wall time per step over a few steps (choice of the execution mode, see choose_exec)."""
+        step = (self.graph_step if self.use_graph else self.train_step) if self.mode == "train" else self.infer_step
+        for _ in range(warmup):
+            step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        dt = (time.perf_counter() - t0) / steps
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     def timed(self, steps, warmup, roofline=True):
         from pointcloud_bridge_amd import ops
@@ -347,7 +379,9 @@ class Run:
         nsampled = 0
         for i in range(steps):
             # HIP events around the roofline kernel on every 10th step (launched eagerly in graph mode)
-            sampled = bool(roofline and i % 10 == 0 and not os.environ.get("PCB_BENCH_NO_ROOFLINE"))
+            # (a captured step launches nothing through the library: its launch durations come from eager steps
+            # outside the timed region, Run.isolated_launches)
+            sampled = bool(roofline and i % 10 == 0 and not self.use_graph and not os.environ.get("PCB_BENCH_NO_ROOFLINE"))
             nsampled += sampled
             ops.kernel_timer_enable(sampled)
             h0 = time.perf_counter()
@@ -383,7 +417,8 @@ class Run:
 
     def close(self):
         from pointcloud_bridge_amd.models import pointnet2_utils as pu
-        pu.set_static_sampling(None)
+        if self.use_graph:
+            pu.set_static_sampling(None)
         pu.set_scene_shard(0, 1)
         if hasattr(self.bucket, "close"):
             self.bucket.close()
@@ -404,6 +439,9 @@ def main():
     ap.add_argument("--data", default="ball", choices=["ball", "bridge"],
                     help="synthetic family: unit-ball clouds, or bridge-like clouds (deck / piers / railings, "
                          "non-uniform density, 20 %% repeated points as the reference's padding produces)")
+    ap.add_argument("--exec", default="auto", choices=["auto", "eager", "graph"],
+                    help="how the training step is issued: eager (kernel by kernel, branch streams), graph (one captured "
+                         "hipGraph per step), auto (time a few steps of both, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other configurations")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -443,11 +481,58 @@ def main():
             raise SystemExit(f"--scaling strong: the global batch of {B} scenes does not split over {world} ranks")
         B //= world
 
-    run = Run(args, args.model, args.precision, B, N, rank, world, device, args.mode, args.data, args.graph, args.loss,
-              args.sync_bn, strong)
+    def make(graph):
+        return Run(args, args.model, args.precision, B, N, rank, world, device, args.mode, args.data, graph, args.loss,
+                   args.sync_bn, strong)
+
+    # Execution mode of the training step.  The eager step (branch streams, sampling of the next batch on a side
+    # stream) needs 7.7-10 ms of host time per step depending on the box's host cores -- as much as the GPU needs --
+    # while the captured step (one hipGraph replay + all-reduce + Adam) needs almost none but keeps ball query and
+    # k-NN of the step on its main path.  Which one is faster depends on the host: `auto` times a few steps of both
+    # and runs the timed region with the faster one (the same decision on every rank: maximum over ranks).
+    exec_mode = "graph" if args.graph else args.exec
+    probes = {}
+    can_graph = (args.mode == "train" and args.model in ("pn2_msg", "pn2_ssg", "dgcnn") and args.loss == "ce"
+                 and not args.dump and not args.no_prefetch)
+    if exec_mode == "auto" and not can_graph:
+        exec_mode = "eager"
+    run = None
+    if exec_mode == "auto":
+        eager = make(False)
+        probes["eager_ms"] = eager.probe() * 1e3
+        try:
+            graph = make(True)
+            probes["graph_ms"] = graph.probe() * 1e3
+        except Exception as e:  # a capture that fails must not cost the run
+            graph = None
+            probes["graph_error"] = f"{type(e).__name__}: {e}"[:200]
+        if graph is not None and probes["graph_ms"] < probes["eager_ms"]:
+            exec_mode, run, other = "graph", graph, eager
+        else:
+            exec_mode, run, other = "eager", eager, graph
+        # launch durations of the roofline family: from eager single-stream steps of whichever run is dropped (the
+        # kernels are the same ones), before it goes
+        from pointcloud_bridge_amd.models import pointnet2_utils as pu
+        iso_other = None
+        if other is not None and not os.environ.get("PCB_BENCH_NO_ROOFLINE"):
+            if other is eager:
+                pu.set_static_sampling(None)          # the eager step samples through its own prefetch pipeline
+            iso_other = other.isolated_launches()
+        if other is not None:
+            other.close()
+            del other
+        if run.use_graph:
+            pu.set_static_sampling(run.static)        # (only the eager steps of the captured run read it)
+        pu.set_scene_shard(rank if strong else 0, world if strong else 1)
+        torch.cuda.empty_cache()
+    else:
+        iso_other = None
+        run = make(exec_mode == "graph")
     res = run.timed(args.steps, args.warmup)
     # (every rank: the steps contain the gradient all-reduce)
-    iso = run.isolated_launches() if not (os.environ.get("PCB_BENCH_NO_ROOFLINE") or args.dump) else None
+    iso = None
+    if not (os.environ.get("PCB_BENCH_NO_ROOFLINE") or args.dump):
+        iso = iso_other if iso_other is not None else run.isolated_launches()
     if args.dump and rank == 0:
         torch.save({"losses": res["losses"], "flat": run.opt.flat.detach().cpu(),
                     "first_grad": getattr(run, "first_grad", torch.zeros(0)).cpu()}, args.dump)
@@ -473,9 +558,10 @@ def main():
         concurrent = None
         if iso and iso["nt_launches"]:
             # the timed region's figures (GEMMs of concurrent chains share the chip) go along for the record
-            c_n = max(res["nt_launches"], 1)
-            concurrent = {"launches": res["nt_launches"], "avg_launch_us": res["nt_ms"] / c_n * 1e3,
-                          "achieved": (res["nt_bytes"] / c_n) / (res["nt_ms"] / c_n * 1e-3) / 1e9 if res["nt_launches"] else 0.0}
+            if res["nt_launches"]:
+                c_n = res["nt_launches"]
+                concurrent = {"launches": c_n, "avg_launch_us": res["nt_ms"] / c_n * 1e3,
+                              "achieved": (res["nt_bytes"] / c_n) / (res["nt_ms"] / c_n * 1e-3) / 1e9}
             res = dict(res, **iso)
         launches = res["nt_launches"]
         alg_bytes = res["nt_bytes"] / max(launches, 1)   # per launch
@@ -505,15 +591,16 @@ def main():
                        "parallelism": f"dp{world} (scenes sharded, {args.scaling} scaling"
                                       + (", SyncBatchNorm" if args.sync_bn and world > 1 else "") + ")",
                        "loss": res["loss"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
-                       "library_launches_per_step": res["lib_launches_per_step"], "graph": bool(args.graph)},
+                       "library_launches_per_step": res["lib_launches_per_step"], "graph": exec_mode == "graph",
+                       "exec": dict({"mode": exec_mode, "requested": "graph" if args.graph else args.exec}, **probes)},
             "roofline": {"bound": "hbm", "kernel": ROOFLINE_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": launches, "avg_launch_us": avg_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "sampling": ("HIP events around every launch of the family in 2 steps run right after the timed "
+                         "sampling": ("HIP events around every launch of the family in 2 eager steps outside the timed "
                                       "region with all chains of the model on one stream (a launch's own duration); "
-                                      "`timed_region` holds the same measurement on every 10th timed step, where GEMMs "
-                                      "of concurrent chains share the chip") if concurrent else
+                                      "`timed_region` (eager execution only) holds the same measurement on every 10th "
+                                      "timed step, where GEMMs of concurrent chains share the chip") if iso else
                                      "HIP events around every launch of the family on every 10th timed step",
                          "timed_region": concurrent,
                          # algorithmic bytes of ALL kernel families of the library over the step time

@@ -445,15 +445,16 @@ def run_branches(device, fns, inputs=()):
     used by the branch streams -- their blocks are not handed out again before that work is done."""
     # (a no-grad pass is host-bound -- 3 ms of enqueueing for 2.7 ms of kernels at B=16 x N=16384 -- and the
     # fork/join calls only add to that: branches are for training steps)
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
     if (not (_branch_streams_on and device.type == "cuda" and len(fns) > 1 and torch.is_grad_enabled())
-            or torch.cuda.is_current_stream_capturing()):
+            or (capturing and os.environ.get("PCB_BRANCH_IN_CAPTURE", "0") != "1")):
         return [fn() for fn in fns]
     main = torch.cuda.current_stream()
     streams = [main] + _branches(device, len(fns) - 1)
     for st in streams[1:]:
         st.wait_stream(main)
         for t in inputs:
-            if t is not None and t.is_cuda:
+            if t is not None and t.is_cuda and not capturing:
                 t.record_stream(st)
     outs = []
     for st, fn in zip(streams, fns):
@@ -461,7 +462,8 @@ def run_branches(device, fns, inputs=()):
             outs.append(fn())
     for st, o in zip(streams[1:], outs[1:]):
         main.wait_stream(st)
-        o.record_stream(main)
+        if not capturing:
+            o.record_stream(main)
     return outs
 
 

@@ -8,6 +8,6 @@ REPO=$PWD
 mkdir -p $REPO/gpurun_out/$NAME
 cd /tmp && export TMPDIR=/tmp
 PCB_BENCH_NO_ROOFLINE=1 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/$NAME -o p --output-format csv -- \
-    python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras "$@" > $REPO/gpurun_out/$NAME/bench.json 2> $REPO/gpurun_out/$NAME/err.log
+    python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --exec eager "$@" > $REPO/gpurun_out/$NAME/bench.json 2> $REPO/gpurun_out/$NAME/err.log
 cd $REPO
 ls gpurun_out/$NAME

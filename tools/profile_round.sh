@@ -12,7 +12,7 @@ stats() {  # name, extra env as VAR=VALUE or "-", bench flags...
     local name=$1 envv=$2; shift 2
     [ "$envv" != "-" ] && export $envv
     PCB_BENCH_NO_ROOFLINE=1 rocprofv3 --kernel-trace --stats -d $OUT/$name -o p --output-format csv -- \
-        python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras "$@" > $OUT/$name.json 2> $OUT/$name.err
+        python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --exec eager "$@" > $OUT/$name.json 2> $OUT/$name.err
     [ "$envv" != "-" ] && unset ${envv%%=*}
     cp $OUT/$name/p_kernel_stats.csv $OUT/${name}_kernel_stats.csv
     echo "$name done"
@@ -20,7 +20,7 @@ stats() {  # name, extra env as VAR=VALUE or "-", bench flags...
 pmc() {  # name, counters...
     local name=$1; shift
     PCB_BRANCH_STREAMS=0 rocprofv3 --pmc "$@" -d $OUT/$name -o p --output-format csv -- \
-        python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-prefetch > $OUT/$name.json 2> $OUT/$name.err
+        python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --exec eager --no-prefetch > $OUT/$name.json 2> $OUT/$name.err
     echo "$name done"
 }
 case "$1" in
@@ -36,7 +36,7 @@ pmc)
     pmc pmc_fetch FETCH_SIZE
     pmc pmc_write WRITE_SIZE
     pmc pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES
-    CMD="PCB_BRANCH_STREAMS=0 rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-prefetch"
+    CMD="PCB_BRANCH_STREAMS=0 rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --exec eager --no-prefetch"
     python3 $REPO/tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_gemm_nt_bf16.json "$CMD"
     python3 $REPO/tools/mfma_util.py $OUT/pmc_mfma $OUT/pmc_mfma_util.json "$CMD"
     cd $REPO && python3 tools/nt_bench.py > $OUT/nt_bench.log 2>&1
