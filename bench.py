@@ -238,15 +238,17 @@ class Run:
         xyz_next = xyz.clone()
         batch = (xyz, colors, labels)
         static = None
-        if hasattr(model, "sa1"):
-            static = pu.StaticSampling(xyz, [model.sa1.npoint, model.sa2.npoint, model.sa3.npoint])
+        if hasattr(model, "static_sampling"):
+            static = model.static_sampling(xyz)
             pu.set_static_sampling(static)
             static.draw()
-            static.compute(xyz)
+            static.compute(xyz_next)
         side = torch.cuda.Stream()
         loss_buf = torch.zeros((), device=self.device)
 
         def fwd_bwd():
+            if static is not None:
+                static.commit()                  # what the previous step computed for this batch becomes live
             loss = self.loss_of(model(xyz, colors), batch)
             if static is not None:
                 side.wait_stream(torch.cuda.current_stream())

@@ -30,6 +30,17 @@ class _SamplingPrefetchMixin:
         # decoder stages: fp3 level 2 <- 3, fp2 level 1 <- 2, fp1 level 0 <- 1
         prefetch_sampling(xyz.contiguous(), [m.npoint for m in sas], balls, [(2, 3, k), (1, 2, k), (0, 1, k)])
 
+    def static_sampling(self, xyz):
+        """A pointnet2_utils.StaticSampling pipeline for steps replayed from a hipGraph: the same coordinate-only
+        work `prefetch` issues (FPS pyramid, ball queries, decoder k-NN and inverted indices), in persistent
+        double-set buffers."""
+        from .pointnet2_utils import StaticSampling
+        sas = (self.sa1, self.sa2, self.sa3)
+        balls = [((m.radius_list, m.nsample_list) if hasattr(m, "radius_list") else ([m.radius], [m.nsample]))
+                 for m in sas]
+        k = 4 if hasattr(self.fp1, "attention") else 3
+        return StaticSampling(xyz, [m.npoint for m in sas], balls, [(2, 3, k), (1, 2, k), (0, 1, k)])
+
     def set_next(self, xyz):
         """Pipelined inference: the coordinates of the batch that FOLLOWS the next forward call.  That
         call starts their coordinate-only work (prefetch) as soon as its own encoder has consumed the

@@ -189,27 +189,38 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
 
 
 class StaticSampling:
-    """The sampling pyramid in persistent device buffers, for steps replayed from a hipGraph.
+    """The coordinate-only results of a step in persistent device buffers, for steps replayed from a hipGraph.
 
-    A captured step cannot draw from the CPU generator or allocate.  So the start indices live in
-    static device tensors that `draw()` refreshes on the host before every replay (same
-    torch.randint calls, same order as farthest_point_sample), and `compute(xyz)` enqueues the FPS
-    pyramid of the NEXT batch into static (idx, new_xyz) buffers -- inside the captured step, on a
-    side stream next to the backward pass.  SetAbstraction / MultiScaleSetAbstraction read the
-    buffers (see _sample) while a pipeline is installed with set_static_sampling()."""
+    A captured step cannot draw from the CPU generator or allocate.  So the FPS start indices live in static
+    device tensors that `draw()` refreshes on the host before every replay (same torch.randint calls, same order
+    as farthest_point_sample), and `compute(xyz_next)` enqueues -- inside the captured step, on a side stream
+    next to the backward pass -- the FPS pyramid of the NEXT batch and, when given, what else depends on
+    coordinates only (`balls`, `propagation` as in prefetch_sampling: ball-query indices per level, the k-NN and
+    the inverted index of each decoder stage).
 
-    def __init__(self, xyz, npoints):
+    Two sets of buffers: compute() writes the STAGING set, commit() -- the first thing a captured step does --
+    copies it into the LIVE set the modules read.  The backward pass of a step still reads the live set (centroid
+    coordinates for the gradient of the coordinate weights, neighbour indices for the scatter) while the side
+    stream already produces the next step's results: with one set those reads raced with that work.
+    SetAbstraction / MultiScaleSetAbstraction / the propagation stages read the live buffers (see _sample,
+    _ball_indices, _nearest, _interp_csr) while a pipeline is installed with set_static_sampling()."""
+
+    def __init__(self, xyz, npoints, balls=None, propagation=None):
         B, N, _ = xyz.shape
         dev = xyz.device
         self.levels = []
+        self.balls = balls
+        self.propagation = list(propagation or ())
+        self.extra = {}   # key -> (live tensors, staging tensors), allocated at the first compute()
         n_in = N
         for s in npoints:
-            self.levels.append({
-                "n_in": n_in, "npoint": int(s),
-                "pinned": torch.zeros(B, dtype=torch.long).pin_memory(),
-                "start": torch.zeros(B, dtype=torch.long, device=dev),
-                "idx": torch.zeros(B, int(s), dtype=torch.long, device=dev),
-                "new_xyz": torch.zeros(B, int(s), 3, dtype=torch.float32, device=dev)})
+            lv = {"n_in": n_in, "npoint": int(s),
+                  "pinned": torch.zeros(B, dtype=torch.long).pin_memory(),
+                  "start": torch.zeros(B, dtype=torch.long, device=dev)}
+            for tag in ("", "_s"):
+                lv["idx" + tag] = torch.zeros(B, int(s), dtype=torch.long, device=dev)
+                lv["new_xyz" + tag] = torch.zeros(B, int(s), 3, dtype=torch.float32, device=dev)
+            self.levels.append(lv)
             n_in = int(s)
 
     def draw(self):
@@ -221,13 +232,46 @@ class StaticSampling:
             lv["pinned"].copy_(torch.randint(0, lv["n_in"], (B * world,), dtype=torch.long)[rank * B:(rank + 1) * B])
             lv["start"].copy_(lv["pinned"], non_blocking=True)
 
+    def _stage(self, key, res):
+        held = self.extra.get(key)
+        if held is None:  # first call: outside the capture (the warm-up steps)
+            held = self.extra[key] = (tuple(torch.empty_like(r) for r in res), tuple(torch.empty_like(r) for r in res))
+        for h, r in zip(held[1], res):
+            h.copy_(r)
+
     def compute(self, xyz):
-        """Enqueue the whole pyramid for `xyz` on the current stream (capturable)."""
+        """Enqueue everything for `xyz` (the NEXT step's coordinates) on the current stream, into the staging set."""
         cur = xyz
+        clouds = [xyz]
+        for l, lv in enumerate(self.levels):
+            ops.furthest_point_sample_into(cur, lv["start"], lv["idx_s"])
+            ops.gather_rows_into(cur, lv["idx_s"], lv["new_xyz_s"])
+            if self.balls is not None and self.balls[l] is not None:
+                radii, nsamples = self.balls[l]
+                self._stage(("ball", l), _ball_indices_now(radii, nsamples, cur, lv["new_xyz_s"]))
+            cur = lv["new_xyz_s"]
+            clouds.append(cur)
+        for fine, coarse, k in self.propagation:
+            nn_res = ops.three_nn(clouds[fine], clouds[coarse], k)
+            self._stage(("nn", fine, coarse, int(k)), nn_res)
+            if torch.is_grad_enabled():
+                self._stage(("csr", fine, coarse, int(k)), rowmlp.build_interp_csr(nn_res[1], clouds[coarse].shape[1]))
+
+    def commit(self):
+        """staging -> live (capturable; the first operation of a captured step)."""
         for lv in self.levels:
-            ops.furthest_point_sample_into(cur, lv["start"], lv["idx"])
-            ops.gather_rows_into(cur, lv["idx"], lv["new_xyz"])
-            cur = lv["new_xyz"]
+            lv["idx"].copy_(lv["idx_s"])
+            lv["new_xyz"].copy_(lv["new_xyz_s"])
+        for live, staged in self.extra.values():
+            for d, r in zip(live, staged):
+                d.copy_(r)
+
+    def _level_of(self, t):
+        """0 for a level-0 cloud (any tensor of the input size), l for the live coordinates of level l, else None."""
+        for l, lv in enumerate(self.levels):
+            if t.data_ptr() == lv["new_xyz"].data_ptr():
+                return l + 1
+        return 0 if t.shape[1] == self.levels[0]["n_in"] else None
 
     def lookup(self, xyz, npoint):
         prev = None
@@ -237,6 +281,21 @@ class StaticSampling:
                     return lv["idx"], lv["new_xyz"]
             prev = lv
         return None
+
+    def lookup_ball(self, radii, nsamples, xyz, new_xyz):
+        l = self._level_of(new_xyz)
+        if l is None or l == 0 or self.balls is None or self.balls[l - 1] is None:
+            return None
+        r0, n0 = self.balls[l - 1]
+        if tuple(float(r) for r in r0) != tuple(float(r) for r in radii) or tuple(int(n) for n in n0) != tuple(int(n) for n in nsamples):
+            return None
+        held = self.extra.get(("ball", l - 1))
+        return None if held is None else held[0]
+
+    def lookup_extra(self, kind, xyz1, xyz2, k):
+        f, c = self._level_of(xyz1), self._level_of(xyz2)
+        held = self.extra.get((kind, f, c, int(k))) if f is not None and c is not None else None
+        return None if held is None else held[0]
 
 
 _static = None
@@ -301,12 +360,20 @@ def _ball_indices_now(radii, nsamples, xyz, new_xyz):
 
 def _ball_indices(radii, nsamples, xyz, new_xyz):
     """Ball-query indices of every scale of a set abstraction: parked by prefetch_sampling or computed now."""
+    if _static is not None:
+        hit = _static.lookup_ball(radii, nsamples, xyz, new_xyz)
+        if hit is not None:
+            return hit
     hit = _take_parked(_ball_key(radii, nsamples, xyz, new_xyz), xyz) if _parked else None
     return hit if hit is not None else _ball_indices_now(radii, nsamples, xyz, new_xyz)
 
 
 def _nearest(xyz1, xyz2, k):
     """(d2, idx) of the k nearest xyz2 points of every xyz1 point: parked by prefetch_sampling or computed now."""
+    if _static is not None:
+        hit = _static.lookup_extra("nn", xyz1, xyz2, k)
+        if hit is not None:
+            return hit
     hit = _take_parked(("nn", xyz1.data_ptr(), xyz2.data_ptr(), int(k)), xyz1) if _parked else None
     return hit if hit is not None else ops.three_nn(xyz1, xyz2, k)
 
@@ -522,7 +589,9 @@ def _propagate_rows(xyz1, xyz2, points1, points2, k):
     S, C = xyz2.shape[1], points2.shape[1]
     if S > 1 and C % rowmlp.mode().q == 0:
         d2, idx = _nearest(xyz1, xyz2, k)
-        csr = _take_parked(("csr", idx.data_ptr())) if _parked else None
+        csr = _static.lookup_extra("csr", xyz1, xyz2, k) if _static is not None else None
+        if csr is None:
+            csr = _take_parked(("csr", idx.data_ptr())) if _parked else None
         skip = None if points1 is None else _channels_last(points1).reshape(B * N, -1)
         return rowmlp.interpolate_concat(skip, _channels_last(points2), d2, idx, csr)
     x = _interpolate(xyz1, xyz2, points2, k)

@@ -473,3 +473,45 @@ def test_confusion_matrices_on_device_equal_the_per_point_loop():
     assert abs(float(m["miou"]) - iou.mean()) < 1e-12
     assert abs(float(m["oa"]) - diag.sum() / cm.sum()) < 1e-9
     assert float(m["iou"][3]) == 0.0   # absent class: IoU 0 (not NaN) and it DOES enter the mean (:826, :846)
+
+
+@pytest.mark.gpu
+def test_captured_pn2_msg_step_equals_the_eager_step():
+    """The captured hipGraph step of bench.py (static sampling pipeline: FPS pyramid, ball queries, decoder k-NN and
+    inverted indices of the NEXT batch computed on a side stream into a staging set, committed at the top of the
+    next replay) against the same step launched kernel by kernel: same batches in the same order, same FPS start
+    indices -> the same gradients up to the run-to-run spread of the step (fp32 atomics in the gathered set
+    abstraction).  With ONE set of static buffers the backward pass read centroid coordinates and neighbour indices
+    that the side stream was already overwriting for the next batch."""
+    import argparse
+    import bench
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models import pointnet2_utils as pu
+    args = argparse.Namespace(no_dropout=True, no_prefetch=False, dump=False)
+    dev = torch.device("cuda", 0)
+    run = bench.Run(args, "pn2_msg", "bf16", 4, 4096, 0, 1, dev, graph=True)
+    try:
+        run.opt.step = lambda *a, **k: None      # parameters stay put: gradients of different steps are comparable
+
+        def pair(step):
+            run.i = 0
+            torch.manual_seed(11)                # FPS start indices of both steps
+            step()                               # computes the pyramid of batch 1 beside its backward pass
+            step()                               # batch 1: forward on that pyramid
+            torch.cuda.synchronize()
+            return run.bucket.flat.clone()
+
+        e1, e2 = pair(run.eager_step), pair(run.eager_step)
+        scale = float(e1.abs().max())
+        spread = float((e1 - e2).abs().max())
+        l2_spread = float((e1 - e2).norm() / e1.norm())
+        for _ in range(2):
+            g = pair(run.graph_step)
+            err = float((g - e1).abs().max())
+            l2 = float((g - e1).norm() / e1.norm())
+            assert err <= 4 * spread + 1e-6 * scale, (err, spread, scale)
+            assert l2 <= 4 * l2_spread + 1e-6, (l2, l2_spread)
+    finally:
+        run.close()
+        pu.set_static_sampling(None)
+        rowmlp.set_precision("fp32")
