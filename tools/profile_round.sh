@@ -31,6 +31,11 @@ stats)
     stats pn2_msg_bf16_infer - --mode infer
     stats dgcnn_bf16 - --model dgcnn
     stats bridgeseg_bf16 - --model bridgeseg
+    stats ptv3_bf16_infer - --model ptv3 --mode infer
+    ;;
+graph)
+    # the captured step: bench.py --exec graph (the stats helper passes --exec eager first; the later flag wins)
+    stats pn2_msg_bf16_graph - --exec graph
     ;;
 pmc)
     pmc pmc_fetch FETCH_SIZE
