@@ -436,6 +436,12 @@ int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const float *scale
                      int ns, int act, int bpro, const void *x, const float *xscale, const float *xshift,
                      int xact, long R, int M, int N, float *workspace, float *dW, int out_cols,
                      int out_perm, void *stream);
+/* Weight AND bias gradient of a conv without BatchNorm (attention[3] / boundary_aware[3] of EnhancedFeaturePropagation,
+ * the classifier convs) in one pass over dy [R,M] and x [R,N]: dW as pcb_gemm_tn_bf16 writes it (apro 0, bpro 0),
+ * dbias[M] = column sums of dy -- accumulated by the same workgroups per row split and summed with the slabs, instead of
+ * a separate pass over dy (pcb_colstats_bf16). */
+int pcb_gemm_tn_bias_bf16(const void *dy, const void *x, long R, int M, int N, float *workspace, float *dW, int out_cols,
+                          int out_perm, float *dbias, void *stream);
 int pcb_gemm_tn_f32(int apro, const void *dz, const void *y, const float *scale, const float *shift,
                     const float *p, const float *q, const float *dout, const unsigned char *argmax,
                     int ns, int act, int bpro, const void *x, const float *xscale, const float *xshift,

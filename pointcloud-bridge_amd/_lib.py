@@ -73,6 +73,7 @@ SIGNATURES = {
     "pcb_gemm_nt_f32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _i, _p],
     "pcb_gemm_tn_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _i, _i, _p],
     "pcb_gemm_tn_f32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p, _p, _i, _i, _p],
+    "pcb_gemm_tn_bias_bf16": [_p, _p, _l, _i, _i, _p, _p, _i, _i, _p, _p],
     "pcb_gemm_tn_workspace": [_l, _i, _i],
     "pcb_bn_bwd_finalize": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "pcb_prep_weights_bf16": [_i, _p, _p],

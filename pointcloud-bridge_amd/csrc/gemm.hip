@@ -887,11 +887,15 @@ __device__ __forceinline__ unsigned xcd_logical(unsigned id, unsigned total)
     return xcd * q + (xcd < rem ? xcd : rem) + slot;
 }
 
-template <int APRO, int BPRO>
+// ASUM (plain A operand only): the column sums of A over the split's rows are stored behind the split's [M,N]
+// slab -- for a conv with a bias that is its bias gradient (sum of dy over the rows), which otherwise costs a
+// pass of its own over dy.  `stride` = floats from one split's slab to the next (M*N, or M*N + M with ASUM).
+template <int APRO, int BPRO, int ASUM = 0>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand B_arg, long R, int M, int N,
-                                                       long rows_per_split, float *__restrict__ part,
+                                                       long rows_per_split, float *__restrict__ part, long stride,
                                                        int tiles_m, int tiles_n)
 {
+    static_assert(!ASUM || APRO == PRO_PLAIN, "column sums of the plain operand only");
     const Operand A = local_copy(A_arg);
     const Operand B = local_copy(B_arg);
     const float a_slope = act_slope(A.act), b_slope = act_slope(B.act);
@@ -946,11 +950,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     const int tr_col = 16 * (grp & 1) + 4 * (gi & 3);
 
     if (r_begin < r_end) fetch(r_begin);
+    float asum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (long r0 = r_begin; r0 < r_end; r0 += TN_RS) {
 #pragma unroll
         for (int i = 0; i < TN_NCH; ++i) {
-            *reinterpret_cast<uint4 *>(&As[(rrow + 16 * i) * TN_LD + chunk * 8]) = ra[i].finish(ka, a_slope);
+            const uint4 av = ra[i].finish(ka, a_slope);
+            *reinterpret_cast<uint4 *>(&As[(rrow + 16 * i) * TN_LD + chunk * 8]) = av;
             *reinterpret_cast<uint4 *>(&Bs[(rrow + 16 * i) * TN_LD + chunk * 8]) = rb[i].finish(kb, b_slope);
+            if (ASUM) {
+                float f[8];
+                unpack8(av, f);  // rows outside the split are zero already
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asum[e] += f[e];
+            }
         }
         __syncthreads();
         if (r0 + TN_RS < r_end) fetch(r0 + TN_RS);
@@ -988,9 +1000,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
                 const int m = m0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 // one plain store per element into this split's slab (summed by reduce_slabs_kernel):
                 // thousands of workgroups adding into one small dW would serialise on its few lines
-                if (m < M && n < N) part[((long)split * M + m) * N + n] = acc[a][b][i];
+                if (m < M && n < N) part[(long)split * stride + (long)m * N + n] = acc[a][b][i];
             }
         }
+    if (ASUM && tile_n == 0) {
+        // the 16 threads that share a column chunk (t & 15) meet in LDS (the stage buffers are idle now), fixed order
+        float *const red = reinterpret_cast<float *>(As);   // [16][128]
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rrow * 128 + chunk * 8 + e] = asum[e];
+        __syncthreads();
+        if (t < 128 && m0 + t < M) {
+            float a = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a += red[i * 128 + t];
+            part[(long)split * stride + (long)M * N + m0 + t] = a;
+        }
+    }
 }
 
 template <int PRO>
@@ -1020,18 +1046,21 @@ void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, 
 
 template <int APRO>
 void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int N, float *part, float *dW,
-               int out_cols, int out_perm, hipStream_t st)
+               int out_cols, int out_perm, hipStream_t st, float *colsum = nullptr)
 {
     long rps;
     // fewer splits while another kernel holds CUs (never more than pcb_gemm_tn_workspace assumed)
     const long splits = pcb_tn_splits(R, M, N, &rps, 512 - 2 * pcb_busy_cus());
     const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
     const dim3 grid((unsigned)(tm * tn * splits));
-    if (bpro == PRO_PLAIN)
-        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, tm, tn);
+    const long stride = (long)M * N + (colsum ? M : 0);
+    if (colsum && APRO == PRO_PLAIN && bpro == PRO_PLAIN)
+        hipLaunchKernelGGL((gemm_tn_kernel<PRO_PLAIN, PRO_PLAIN, 1>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
+    else if (bpro == PRO_PLAIN)
+        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, tm, tn);
-    (void)pcb_reduce_slabs(part, (int)splits, (long)M * N, dW, N, out_cols, out_perm, 8, st);
+        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
+    (void)pcb_reduce_slabs_vec(part, (int)splits, stride, (long)M * N, dW, N, out_cols, out_perm, 8, colsum, M, st);
 }
 
 inline bool bad_dim(long v) { return v <= 0 || (v & 7) != 0; }
@@ -1183,6 +1212,21 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
     else
         launch_tn<PRO_DY_POOL>(A, B, bpro, R, M, N, workspace, dW, out_cols, out_perm, st);
     pcb_account((apro == PRO_DY ? 4.0 : 2.0) * R * M + (apro == PRO_DY_POOL ? 5.0 * (double)(R / (ns > 0 ? ns : 1)) * M : 0.0) + 2.0 * R * N);
+    return pcb_check_launch();
+}
+
+// Weight AND bias gradient of a conv without BatchNorm in one pass over dy: dW = dy^T x, dbias = column sums of dy.
+extern "C" int pcb_gemm_tn_bias_bf16(const void *dy, const void *x, long R, int M, int N, float *workspace, float *dW,
+                                     int out_cols, int out_perm, float *dbias, void *stream)
+{
+    if (!dy || !x || !dW || !dbias || !workspace || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (out_cols <= 0) { out_cols = N; out_perm = 0; }
+    if (out_cols > N) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(M) || bad_dim(N)) return PCB_ERR_UNSUPPORTED;
+    const Operand A = make_operand(dy, nullptr, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
+    const Operand B = make_operand(x, nullptr, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
+    launch_tn<PRO_PLAIN>(A, B, PRO_PLAIN, R, M, N, workspace, dW, out_cols, out_perm, (hipStream_t)stream, dbias);
+    pcb_account(2.0 * R * M + 2.0 * R * N);
     return pcb_check_launch();
 }
 

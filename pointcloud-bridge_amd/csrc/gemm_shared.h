@@ -37,3 +37,8 @@ long pcb_tn_splits(long R, int M, int N, long *rows_per_split, long target);
 // parked and run with the other parked sums in one launch.  quantum: 8 (bf16 rows) or 4 (fp32 rows).
 int pcb_reduce_slabs(const float *part, int splits, long elems, float *dW, int N, int out_cols, int out_perm,
                      int quantum, hipStream_t st);
+
+// pcb_reduce_slabs with slabs `stride` floats apart and, optionally, `vlen` further sums per slab stored behind
+// its [M,N] part (they go to `vec`): the bias gradient of pcb_gemm_tn_bias_bf16.
+int pcb_reduce_slabs_vec(const float *part, int splits, long stride, long elems, float *dW, int N, int out_cols,
+                         int out_perm, int quantum, float *vec, int vlen, hipStream_t st);

@@ -44,6 +44,9 @@ struct PendingReduce {
     float *dW;
     long elems;
     int splits, N, k, perm, quantum;
+    long stride;   // floats from one split's slab to the next (>= elems)
+    float *vec;    // optional: `vlen` more sums stored behind each slab's [M,N] part (column sums of dy = a bias gradient)
+    int vlen;
 };
 struct ReduceBatch {
     PendingReduce e[kMaxPending];
@@ -53,17 +56,18 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch ba
     __shared__ float red[16][64];
     const PendingReduce r = batch.e[blockIdx.y];
     const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
-    for (long e0 = (long)blockIdx.x * 64; e0 < r.elems; e0 += (long)gridDim.x * 64) {
+    const long total = r.elems + (r.vec ? r.vlen : 0);
+    for (long e0 = (long)blockIdx.x * 64; e0 < total; e0 += (long)gridDim.x * 64) {
         const long e = e0 + ex;
         float a = 0.0f;
-        if (e < r.elems) {
+        if (e < total) {
             // eight splits' loads in flight per step, adds in split order
             for (int s0 = sy; s0 < r.splits; s0 += 16 * 8) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int sp = s0 + 16 * u;
-                    const float x = r.part[(long)(sp < r.splits ? sp : r.splits - 1) * r.elems + e];
+                    const float x = r.part[(long)(sp < r.splits ? sp : r.splits - 1) * r.stride + e];
                     v[u] = sp < r.splits ? x : 0.0f;
                 }
 #pragma unroll
@@ -72,13 +76,17 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch ba
         }
         red[sy][ex] = a;
         __syncthreads();
-        if (sy == 0 && e < r.elems) {
+        if (sy == 0 && e < total) {
             float t = 0.0f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) t += red[i][ex];
-            const long m = e / r.N;
-            const int c = real_column((int)(e - m * r.N), r.k, r.perm, r.quantum);
-            if (c >= 0) r.dW[m * r.k + c] = t;
+            if (e >= r.elems) {
+                r.vec[e - r.elems] = t;
+            } else {
+                const long m = e / r.N;
+                const int c = real_column((int)(e - m * r.N), r.k, r.perm, r.quantum);
+                if (c >= 0) r.dW[m * r.k + c] = t;
+            }
         }
         __syncthreads();
     }
@@ -89,7 +97,7 @@ thread_local int g_npending = -1;  // < 0: every reduction runs right behind its
 int launch_reduce_batch(const ReduceBatch &batch, int n, hipStream_t st)
 {
     long most = 0;
-    for (int i = 0; i < n; ++i) most = batch.e[i].elems > most ? batch.e[i].elems : most;
+    for (int i = 0; i < n; ++i) most = batch.e[i].elems + batch.e[i].vlen > most ? batch.e[i].elems + batch.e[i].vlen : most;
     long blocks = (most + 63) / 64;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(1024), 0, st, batch);
@@ -355,7 +363,13 @@ long pcb_tn_splits(long R, int M, int N, long *rows_per_split, long target)
 int pcb_reduce_slabs(const float *part, int splits, long elems, float *dW, int N, int out_cols, int out_perm,
                      int quantum, hipStream_t st)
 {
-    const PendingReduce r = {part, dW, elems, splits, N, out_cols, out_perm, quantum};
+    return pcb_reduce_slabs_vec(part, splits, elems, elems, dW, N, out_cols, out_perm, quantum, nullptr, 0, st);
+}
+
+int pcb_reduce_slabs_vec(const float *part, int splits, long stride, long elems, float *dW, int N, int out_cols,
+                         int out_perm, int quantum, float *vec, int vlen, hipStream_t st)
+{
+    const PendingReduce r = {part, dW, elems, splits, N, out_cols, out_perm, quantum, stride, vec, vec ? vlen : 0};
     if (g_npending >= 0 && g_npending < kMaxPending) {
         g_pending.e[g_npending++] = r;
         return PCB_OK;
@@ -395,7 +409,7 @@ long pcb_gemm_tn_workspace(long R, int M, int N)
 {
     if (R <= 0 || M <= 0 || N <= 0) return 0;
     long rps;
-    return pcb_tn_splits(R, M, N, &rps, 512) * (long)M * N;
+    return pcb_tn_splits(R, M, N, &rps, 512) * ((long)M * N + M);  // + M: the column sums pcb_gemm_tn_bias_* keeps per split
 }
 
 int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *scale, const float *mean,

@@ -740,21 +740,28 @@ class _LinearBias(torch.autograd.Function):
         dw = torch.empty(npad, k, dtype=torch.float32, device=dev)
         lib = _lib.load()
         ws = torch.empty(lib.pcb_gemm_tn_workspace(R, npad, kp), dtype=torch.float32, device=dev)
-        sums = torch.zeros(2, npad, dtype=torch.float32, device=dev)
+        fused_bias = has_bias and m.sfx == "bf16"   # the bias gradient out of the weight-gradient pass over dy
+        db = torch.empty(npad, dtype=torch.float32, device=dev) if fused_bias else None
+        sums = torch.zeros(2, npad, dtype=torch.float32, device=dev) if has_bias and not fused_bias else None
         with on_device(dev):
             if wt is not None:
                 dx = torch.empty(R, kp, dtype=m.dtype, device=dev)
                 _launch("pcb_gemm_nt_" + m.sfx, 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 0, 0, wt.data_ptr(),
                         R, kp, npad, dx.data_ptr(), 0, 0)
             # dW straight in the real [npad, k] layout (the padding columns of x dropped)
-            _launch("pcb_gemm_tn_" + m.sfx, 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
-                    0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr(), k, 0)
-            if has_bias:
-                _launch("pcb_colstats_" + m.sfx, R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
+            if fused_bias:
+                _launch("pcb_gemm_tn_bias_bf16", 2 * R * (npad + kp), gy.data_ptr(), x.data_ptr(), R, npad, kp, ws.data_ptr(),
+                        dw.data_ptr(), k, 0, db.data_ptr())
+            else:
+                _launch("pcb_gemm_tn_" + m.sfx, 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
+                        0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr(), k, 0)
+                if has_bias:
+                    _launch("pcb_colstats_" + m.sfx, R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
+                    db = sums[0]
         if not out_gap:
-            return dx, dw[:n].reshape(wshape), (sums[0, :n].clone() if has_bias else None), None, None
+            return dx, dw[:n].reshape(wshape), (db[:n].clone() if has_bias else None), None, None
         rows = _gap_row_index(n, out_gap, m.q, dev)
-        return dx, dw[rows].reshape(wshape), (sums[0, rows] if has_bias else None), None, None
+        return dx, dw[rows].reshape(wshape), (db[rows] if has_bias else None), None, None
 
 
 def conv_rows(conv, x, out_dtype=None, out_gap=0):

@@ -515,3 +515,35 @@ def test_captured_pn2_msg_step_equals_the_eager_step():
         run.close()
         pu.set_static_sampling(None)
         rowmlp.set_precision("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,K,n,gap", [(4096, 16, 40, 0), (5000, 128, 5, 0), (70000, 64, 259, 3)])
+def test_bf16_conv_rows_bias_gradient_from_the_weight_gradient_pass(R, K, n, gap):
+    """A conv without BatchNorm in bf16 mode: dbias comes out of pcb_gemm_tn_bias_bf16 (column sums of dy kept per
+    row split beside the dW slabs) -- against fp32 torch on the same bf16 operands: outputs, dx, dW, dbias."""
+    from pointcloud_bridge_amd import rowmlp
+    rowmlp.set_precision("bf16")
+    try:
+        torch.manual_seed(R + n)
+        conv = torch.nn.Conv1d(K, n, 1).cuda()
+        x = torch.randn(R, K, device="cuda").to(torch.bfloat16).requires_grad_(True)
+        y = rowmlp.conv_rows(conv, x, out_gap=gap)
+        y = rowmlp.ungap_rows(y, -gap) if gap else y
+        g = torch.randn(R, n, device="cuda").to(torch.bfloat16)
+        y.backward(g)
+        xr = x.detach().float().requires_grad_(True)
+        w = conv.weight.detach().view(n, K).to(torch.bfloat16).float().requires_grad_(True)
+        b = conv.bias.detach().clone().requires_grad_(True)
+        ref = xr @ w.t() + b
+        ref.backward(g.float())
+
+        def rel(a, r):
+            return float((a.float() - r).abs().max() / r.abs().max())
+
+        assert rel(y, ref.detach()) < 1e-2
+        assert rel(x.grad, xr.grad) < 1e-2
+        assert rel(conv.weight.grad.view(n, K), w.grad) < 2e-3
+        assert rel(conv.bias.grad, b.grad) < 1e-4     # fp32 sums of the bf16 dy: only the summation order differs
+    finally:
+        rowmlp.set_precision("fp32")
