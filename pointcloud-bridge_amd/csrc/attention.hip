@@ -148,10 +148,13 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_fwd_bf16_kernel(const
             psum += __shfl_xor(psum, 32);
             l_run = fmaf(l_run, alpha, psum);
             m_run = m_new;
+            // the running maximum settles after the first tiles: rescale only when some query's changed
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int d = 0; d < DT; ++d)
+                for (int d = 0; d < DT; ++d)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+                    for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+            }
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 bf16x8 pf;

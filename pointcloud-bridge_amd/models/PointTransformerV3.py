@@ -5,7 +5,7 @@ layouts (xyz [B,N,3], features [B,N,C-3] -> logits [B,N,classes]).
 What is native here is the operator the row names: the global attention of PointAttention.forward
 (reference :64-117, F.scaled_dot_product_attention at :102) as one flash-attention pass over the qkv projection
 exactly as the reference lays it out (`ops.attention` -> csrc/attention.hip: no [N,N] tensor, no permute copies,
-1.3-1.6x the throughput of the framework's own fused attention at head_dim 192).  It serves the inference path
+1.3-1.7x the throughput of the framework's own fused attention at head_dim 192).  It serves the inference path
 (no gradients): bf16 mode (`rowmlp.set_precision("bf16")`) runs the token pipeline in bf16 -- the dense layers
 (qkv / proj / GEGLU feed-forward / head) are plain library GEMMs (`F.linear`), LayerNorm / GELU / residuals ATen
 row ops -- with the attention on the library kernel.  The fp32 mode, and any call that needs gradients, is the
