@@ -572,7 +572,10 @@ def main():
         step_s = res["ms_per_step"] * 1e-3
         whole = res["lib_bytes_per_step"] / step_s / 1e9
         workload = (f"{args.model} "
-                    + (("fwd+" + ("CE" if args.loss == "ce" else "BridgeStructureLoss") + "+bwd+overlapped flat grad-allreduce+Adam")
+                    + (("fwd+" + ("CE" if args.loss == "ce" else "BridgeStructureLoss") + "+bwd+"
+                        + ("flat gradient packing" if world == 1 else
+                           ("one flat grad-allreduce" if exec_mode == "graph" else "overlapped bucketed grad-allreduce"))
+                        + "+Adam" + (", captured hipGraph step" if exec_mode == "graph" else ""))
                        if args.mode == "train" else
                        ("eval-mode forward+CE" + (", next batch FPS pipelined" if prefetching else "")))
                     + f", B={B} scenes/GPU x N={N} pts, "
