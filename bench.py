@@ -275,7 +275,8 @@ class Run:
         graph = torch.cuda.CUDAGraph()
         if static is not None:
             static.draw()
-        with torch.cuda.graph(graph):
+        # (thread_local: the process group's watchdog thread may query events while this thread captures)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             fwd_bwd()
         grads = [p.grad for p in self.params if p.grad is not None]  # the graph's fixed tensors
 
@@ -502,12 +503,23 @@ def main():
     if exec_mode == "auto":
         eager = make(False)
         probes["eager_ms"] = eager.probe() * 1e3
+        graph, ok = None, 1
         try:
             graph = make(True)
-            probes["graph_ms"] = graph.probe() * 1e3
         except Exception as e:  # a capture that fails must not cost the run
-            graph = None
+            ok = 0
             probes["graph_error"] = f"{type(e).__name__}: {e}"[:200]
+        if world > 1:
+            # the two modes exchange gradients differently (buckets vs one flat all-reduce): every rank must take
+            # the same one, so a capture that failed anywhere sends all ranks to the eager step
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            probes["graph_ms"] = graph.probe() * 1e3
+        elif graph is not None:
+            graph.close()
+            graph = None
         if graph is not None and probes["graph_ms"] < probes["eager_ms"]:
             exec_mode, run, other = "graph", graph, eager
         else:
