@@ -97,9 +97,15 @@ def build_model(name, num_classes=5):
 
 
 def loss_fn(logits, labels, channel_dim):
+    """nn.CrossEntropyLoss() of the trainers (train_MulSca_PN2.py:161 on [B,C,N]; train_DGCNN.py:177-197 on
+    [B*N,C]): GPU logits go through the library's one-pass kernel (losses.cross_entropy), the CPU port's through
+    F.cross_entropy."""
+    if logits.is_cuda:
+        from pointcloud_bridge_amd.losses import cross_entropy
+        return cross_entropy(logits, labels, channels_last=(channel_dim != 1))
     if channel_dim == 1:
-        return F.cross_entropy(logits, labels)           # train_MulSca_PN2.py:161
-    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))  # train_DGCNN.py:177-197
+        return F.cross_entropy(logits, labels)
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))
 
 
 def cpu_baseline(model_name, N, budget_s=25.0):
@@ -346,17 +352,24 @@ class Run:
         return {"nt_launches": launches, "nt_ms": kernel_ms, "nt_bytes": nt_bytes,
                 "lib_launches_per_step": all_n / steps, "lib_bytes_per_step": all_bytes / steps}
 
-    def probe(self, steps=6, warmup=5):
-        """Wall time per step over a few steps (choice of the execution mode, see choose_exec)."""
+    def probe(self, steps=5, warmup=5, windows=3):
+        """Wall time per step over a few steps (choice of the execution mode, see choose_exec): the fastest of
+        `windows` windows of `steps` steps -- single windows were seen 50 % off on some boxes (13.2 ms for a mode
+        whose timed region then ran at 8.1), which flipped the choice."""
         step = (self.graph_step if self.use_graph else self.train_step) if self.mode == "train" else self.infer_step
         for _ in range(warmup):
             step()
-        self.fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        self.fence()
-        dt = (time.perf_counter() - t0) / steps
+        gc.collect()   # measured like the timed region: no cyclic collections inside (see timed)
+        gc.disable()
+        dt = float("inf")
+        for _ in range(windows):
+            self.fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            self.fence()
+            dt = min(dt, (time.perf_counter() - t0) / steps)
+        gc.enable()
         if self.world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -492,23 +492,26 @@ int pcb_gemm_nt_red_f32(int pro, const void *a0, const void *a1, const float *sc
                         const float *red_scale, const float *red_shift, const float *red_mean,
                         const float *red_invstd, int red_act, float *red_sums, int nparts, void *stream);
 
-/* Backward sums only (no dy written): sums += (sum du, sum du*xhat) for a dense dz ... */
+/* Backward sums only (no dy written): (sum du, sum du*xhat) for a dense dz.  sums = [nparts][2][C]:
+ * nparts > 1 -- one workgroup per slab, EVERY slab written (idle ones with zeros), no atomics, summed
+ * in slab order by pcb_bn_bwd_finalize(sums, nparts, ...) (1 < nparts <= 768);  nparts == 1 -- a
+ * single slab that must be zero on entry and is accumulated with fp32 atomics. */
 int pcb_bn_act_bwd_reduce_bf16(const void *dz, const void *y, const float *scale, const float *shift,
                                const float *mean, const float *invstd, long rows, int C, int act,
-                               float *sums, void *stream);
+                               float *sums, int nparts, void *stream);
 int pcb_bn_act_bwd_reduce_f32(const void *dz, const void *y, const float *scale, const float *shift,
                               const float *mean, const float *invstd, long rows, int C, int act,
-                              float *sums, void *stream);
+                              float *sums, int nparts, void *stream);
 
 /* ... and for a max-pooled layer (dout [groups,C] fp32, argmax [groups,C] uint8). */
 int pcb_bn_act_max_bwd_reduce_bf16(const float *dout, const unsigned char *argmax, const void *y,
                                    const float *scale, const float *shift, const float *mean,
                                    const float *invstd, long groups, int ns, int C, int act, float *sums,
-                                   void *stream);
+                                   int nparts, void *stream);
 int pcb_bn_act_max_bwd_reduce_f32(const float *dout, const unsigned char *argmax, const void *y,
                                   const float *scale, const float *shift, const float *mean,
                                   const float *invstd, long groups, int ns, int C, int act, float *sums,
-                                  void *stream);
+                                  int nparts, void *stream);
 
 /*
  * Interpolation written straight into the row buffer of the following GEMM
@@ -697,6 +700,22 @@ int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *
                         const float *p, const float *q, const float *dout, const unsigned char *argmax, int act,
                         const int64_t *idx, int B, int N, int S, int ns, int C, const float *xyz,
                         const float *ctr, float *du, float *dv, float *dwx, void *stream);
+
+/*
+ * Per-point cross entropy of the segmentation trainers (`criterion = nn.CrossEntropyLoss()` on [B,C,N]
+ * logits vs [B,N] labels, train_MulSca_PN2.py:161; on [B*N,C] in train_DGCNN.py:177-197), mean over the
+ * points whose label is not ignore_index, as one pass over the logits ROWS: logits = R rows of C <= 64
+ * fp32 values, `ld` floats apart (the network's last GEMM output, read in place); labels [R] int64.
+ * fwd: partials = 2 * pcb_cross_entropy_partials(R) floats of scratch; loss_count[0] = the loss,
+ * loss_count[1] = number of counted points.  bwd: dlogits [R,C] contiguous =
+ * (softmax - onehot) * grad_out[0] / count (zero rows for ignored points); grad_out = one float on the device.
+ * Kernels only (no atomics, no memset): valid inside a captured hipGraph.
+ */
+int pcb_cross_entropy_partials(long R);
+int pcb_cross_entropy_fwd(const float *logits, long ld, const int64_t *labels, long R, int C, long ignore_index,
+                          float *partials, float *loss_count, void *stream);
+int pcb_cross_entropy_bwd(const float *logits, long ld, const int64_t *labels, long R, int C, long ignore_index,
+                          const float *loss_count, const float *grad_out, float *dlogits, void *stream);
 
 /*
  * Instruments of bench.py (off unless armed; the only other process-wide state besides the hint):

@@ -111,10 +111,13 @@ SIGNATURES = {
     "pcb_timer_read": [_i, _p, _p, _p],
     "pcb_gemm_nt_red_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     "pcb_gemm_nt_red_f32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p],
-    "pcb_bn_act_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p],
-    "pcb_bn_act_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p],
-    "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
-    "pcb_bn_act_max_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
+    "pcb_bn_act_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _i, _p],
+    "pcb_bn_act_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _i, _p],
+    "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _i, _p],
+    "pcb_bn_act_max_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _i, _p],
+    "pcb_cross_entropy_partials": [_l],
+    "pcb_cross_entropy_fwd": [_p, _l, _p, _l, _i, _l, _p, _p, _p],
+    "pcb_cross_entropy_bwd": [_p, _l, _p, _l, _i, _l, _p, _p, _p, _p],
 }
 
 _lib = None

@@ -57,7 +57,33 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch ba
     const PendingReduce r = batch.e[blockIdx.y];
     const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
     const long total = r.elems + (r.vec ? r.vlen : 0);
-    for (long e0 = (long)blockIdx.x * 64; e0 < total; e0 += (long)gridDim.x * 64) {
+    if (r.splits <= 16) {
+        // few slabs of a large matrix (the wide layers: 6 slabs of 1536 x 1024): one element per lane, all
+        // slabs' loads in flight, adds in split order -- no LDS, no idle split-lanes
+        for (long e = (long)blockIdx.x * 1024 + threadIdx.x; e < total; e += (long)gridDim.x * 1024) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float x = r.part[(long)(u < r.splits ? u : r.splits - 1) * r.stride + e];
+                v[u] = u < r.splits ? x : 0.0f;
+            }
+            float t = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += v[u];
+            if (e >= r.elems) {
+                r.vec[e - r.elems] = t;
+            } else {
+                const long m = e / r.N;
+                const int c = real_column((int)(e - m * r.N), r.k, r.perm, r.quantum);
+                if (c >= 0) r.dW[m * r.k + c] = t;
+            }
+        }
+        return;
+    }
+    // many slabs: at most 1024 workgroups walk the 64-element chunks (more, shorter-lived ones measured slower)
+    const long nblk = gridDim.x < 1024 ? gridDim.x : 1024;
+    if (blockIdx.x >= nblk) return;
+    for (long e0 = (long)blockIdx.x * 64; e0 < total; e0 += nblk * 64) {
         const long e = e0 + ex;
         float a = 0.0f;
         if (e < total) {
@@ -99,7 +125,7 @@ int launch_reduce_batch(const ReduceBatch &batch, int n, hipStream_t st)
     long most = 0;
     for (int i = 0; i < n; ++i) most = batch.e[i].elems + batch.e[i].vlen > most ? batch.e[i].elems + batch.e[i].vlen : most;
     long blocks = (most + 63) / 64;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(1024), 0, st, batch);
     return pcb_check_launch();
 }

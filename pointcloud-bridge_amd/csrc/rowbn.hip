@@ -14,6 +14,7 @@
 //   *_bwd_apply     one pass:  dy = scale * (du - s1/R - xhat * s2/R)      (operand of dgrad/wgrad)
 // Every kernel moves 16-byte vectors (8 bf16 or 4 fp32 channels per lane, rowvec.h) and keeps fp32
 // in registers.
+#include "gemm_shared.h"
 #include "rowvec.h"
 
 namespace {
@@ -285,15 +286,30 @@ __global__ __launch_bounds__(kThreads) void bn_act_bwd_reduce_kernel(
             mu[i] = mean[cc * E + i];
             is[i] = invstd[cc * E + i];
         }
-        for (long r = (long)blockIdx.x * RT + rl; r < rows; r += (long)gridDim.x * RT) {
-            float fy[E], fd[E];
-            RowVec<T>::unpack(y[r * CT + cc], fy);
-            RowVec<T>::unpack(dz[r * CT + cc], fd);
+        // four rows' loads (8 x 16 bytes) in flight per lane and step; rows past the end are read from
+        // the last row and masked, so the loads stay unconditional
+        const long step = (long)gridDim.x * RT;
+        for (long r0 = (long)blockIdx.x * RT + rl; r0 < rows; r0 += 4 * step) {
+            uint4 vy[4], vd[4];
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const float du = fd[i] * act_grad(fmaf(fy[i], sc[i], sh[i]), act);
-                s1[i] += du;
-                s2[i] = fmaf(du, (fy[i] - mu[i]) * is[i], s2[i]);
+            for (int u = 0; u < 4; ++u) {
+                const long r = r0 + u * step;
+                const long rs = r < rows ? r : rows - 1;
+                vy[u] = y[rs * CT + cc];
+                vd[u] = dz[rs * CT + cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float fy[E], fd[E];
+                RowVec<T>::unpack(vy[u], fy);
+                RowVec<T>::unpack(vd[u], fd);
+                const float keep = (r0 + u * step < rows) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const float du = keep * fd[i] * act_grad(fmaf(fy[i], sc[i], sh[i]), act);
+                    s1[i] += du;
+                    s2[i] = fmaf(du, (fy[i] - mu[i]) * is[i], s2[i]);
+                }
             }
         }
     }
@@ -549,14 +565,19 @@ int bn_act_max(const void *y, const float *scale, const float *shift, long group
 
 template <typename T>
 int bn_act_bwd_reduce(const void *dz, const void *y, const float *scale, const float *shift, const float *mean,
-                      const float *invstd, long rows, int C, int act, float *sums, void *stream)
+                      const float *invstd, long rows, int C, int act, float *sums, int nparts, void *stream)
 {
     if (!dz || !y || !scale || !shift || !mean || !invstd || !sums || rows <= 0) return PCB_ERR_INVALID_ARG;
+    if (nparts < 1 || nparts > PCB_MAX_SLABS) return PCB_ERR_INVALID_ARG;
     if (bad_c<T>(C)) return PCB_ERR_UNSUPPORTED;
     const int RT = kThreads / (C / RowVec<T>::E);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(grid_for(rows, RT * 8, 2048)), dim3(kThreads), 0,
+    // nparts > 1: one workgroup per slab, every slab written (no atomics: thousands of workgroups adding
+    // into the same 2C words serialise at the memory side -- measured 62 us for a 25 us pass);
+    // nparts == 1: a single [2][C] slab, zero on entry, accumulated with atomics by a few workgroups
+    const int grid = nparts > 1 ? nparts : grid_for(rows, RT * 32, 256);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(grid), dim3(kThreads), 0,
                        (hipStream_t)stream, (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd,
-                       rows, C, slope_of(act), sums, 0);
+                       rows, C, slope_of(act), sums, nparts > 1 ? 1 : 0);
     pcb_account(2.0 * sizeof(T) * rows * C);
     return pcb_check_launch();
 }
@@ -564,16 +585,18 @@ int bn_act_bwd_reduce(const void *dz, const void *y, const float *scale, const f
 template <typename T>
 int bn_act_max_bwd_reduce(const float *dout, const unsigned char *argmax, const void *y, const float *scale,
                           const float *shift, const float *mean, const float *invstd, long groups, int ns, int C,
-                          int act, float *sums, void *stream)
+                          int act, float *sums, int nparts, void *stream)
 {
     if (!dout || !argmax || !y || !scale || !shift || !mean || !invstd || !sums || groups <= 0 || ns <= 0 ||
         ns > 255)
         return PCB_ERR_INVALID_ARG;
+    if (nparts < 1 || nparts > PCB_MAX_SLABS) return PCB_ERR_INVALID_ARG;
     if (bad_c<T>(C)) return PCB_ERR_UNSUPPORTED;
     const int RT = kThreads / (C / RowVec<T>::E);
-    hipLaunchKernelGGL(bn_max_bwd_reduce_kernel<T>, dim3(grid_for(groups, RT * 4, 2048)), dim3(kThreads), 0,
+    const int grid = nparts > 1 ? nparts : grid_for(groups, RT * 16, 256);  // see bn_act_bwd_reduce
+    hipLaunchKernelGGL(bn_max_bwd_reduce_kernel<T>, dim3(grid), dim3(kThreads), 0,
                        (hipStream_t)stream, dout, argmax, (const T *)y, scale, shift, mean, invstd, groups,
-                       C, ns, slope_of(act), sums, 0);
+                       C, ns, slope_of(act), sums, nparts > 1 ? 1 : 0);
     pcb_account((5.0 + sizeof(T)) * groups * C);
     return pcb_check_launch();
 }
@@ -584,7 +607,7 @@ int bn_act_bwd(const void *dz, const void *y, const float *scale, const float *s
 {
     if (!dy) return PCB_ERR_INVALID_ARG;
     // sums [2,C] must be zero on entry; it returns (dbeta, dgamma) = (s1, s2)
-    const int st = bn_act_bwd_reduce<T>(dz, y, scale, shift, mean, invstd, rows, C, act, sums, stream);
+    const int st = bn_act_bwd_reduce<T>(dz, y, scale, shift, mean, invstd, rows, C, act, sums, 1, stream);
     if (st != PCB_OK) return st;
     const long nvec = rows * (C / RowVec<T>::E);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(nvec)), dim3(kThreads), 0, (hipStream_t)stream,
@@ -600,7 +623,7 @@ int bn_act_max_bwd(const float *dout, const unsigned char *argmax, const void *y
                    int use_batch_stats, float *sums, void *dy, void *stream)
 {
     if (!dy) return PCB_ERR_INVALID_ARG;
-    const int st = bn_act_max_bwd_reduce<T>(dout, argmax, y, scale, shift, mean, invstd, groups, ns, C, act, sums, stream);
+    const int st = bn_act_max_bwd_reduce<T>(dout, argmax, y, scale, shift, mean, invstd, groups, ns, C, act, sums, 1, stream);
     if (st != PCB_OK) return st;
     const long rows = groups * ns;
     const long nvec = rows * (C / RowVec<T>::E);
@@ -757,27 +780,27 @@ int pcb_group_rows_f32_bwd(const void *grad_rows, const int64_t *idx, int B, int
 }
 
 int pcb_bn_act_bwd_reduce_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *mean,
-                               const float *invstd, long rows, int C, int act, float *sums, void *stream)
+                               const float *invstd, long rows, int C, int act, float *sums, int nparts, void *stream)
 {
-    return bn_act_bwd_reduce<pcb_bf16>(dz, y, scale, shift, mean, invstd, rows, C, act, sums, stream);
+    return bn_act_bwd_reduce<pcb_bf16>(dz, y, scale, shift, mean, invstd, rows, C, act, sums, nparts, stream);
 }
 int pcb_bn_act_bwd_reduce_f32(const void *dz, const void *y, const float *scale, const float *shift, const float *mean,
-                              const float *invstd, long rows, int C, int act, float *sums, void *stream)
+                              const float *invstd, long rows, int C, int act, float *sums, int nparts, void *stream)
 {
-    return bn_act_bwd_reduce<float>(dz, y, scale, shift, mean, invstd, rows, C, act, sums, stream);
+    return bn_act_bwd_reduce<float>(dz, y, scale, shift, mean, invstd, rows, C, act, sums, nparts, stream);
 }
 
 int pcb_bn_act_max_bwd_reduce_bf16(const float *dout, const unsigned char *argmax, const void *y, const float *scale,
                                    const float *shift, const float *mean, const float *invstd, long groups, int ns,
-                                   int C, int act, float *sums, void *stream)
+                                   int C, int act, float *sums, int nparts, void *stream)
 {
-    return bn_act_max_bwd_reduce<pcb_bf16>(dout, argmax, y, scale, shift, mean, invstd, groups, ns, C, act, sums, stream);
+    return bn_act_max_bwd_reduce<pcb_bf16>(dout, argmax, y, scale, shift, mean, invstd, groups, ns, C, act, sums, nparts, stream);
 }
 int pcb_bn_act_max_bwd_reduce_f32(const float *dout, const unsigned char *argmax, const void *y, const float *scale,
                                   const float *shift, const float *mean, const float *invstd, long groups, int ns,
-                                  int C, int act, float *sums, void *stream)
+                                  int C, int act, float *sums, int nparts, void *stream)
 {
-    return bn_act_max_bwd_reduce<float>(dout, argmax, y, scale, shift, mean, invstd, groups, ns, C, act, sums, stream);
+    return bn_act_max_bwd_reduce<float>(dout, argmax, y, scale, shift, mean, invstd, groups, ns, C, act, sums, nparts, stream);
 }
 
 int pcb_gate_bf16(const void *x, const void *a, void *out, long n, void *stream) { return gate<pcb_bf16>(x, a, out, n, stream); }

@@ -521,11 +521,26 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
             if (have_parts) {
                 sums = parts;
                 nparts = have_nparts;
+            } else if (parts && parts_slabs > 1) {
+                // the stack's top layer (nobody above it computed its sums): one slab per workgroup of the
+                // reduction pass, summed in slab order by the finalize kernel like the RED epilogue's
+                const long units = pooled ? R / pool : R;
+                const long lanes = 256 / (a.C / op.quantum) > 0 ? 256 / (a.C / op.quantum) : 1;
+                long want = (units + lanes * 4 - 1) / (lanes * 4);
+                if (want > 768) want = 768;
+                if (want > parts_slabs) want = parts_slabs;
+                nparts = want < 2 ? 2 : (int)want;
+                sums = parts;
+                if (pooled)
+                    PCB_TRY(op.max_bwd_reduce(dout, argmax, a.y, scale, shift, mean, invstd, R / pool, pool, a.C, act, parts,
+                                              nparts, stream));
+                else
+                    PCB_TRY(op.bwd_reduce(dz, a.y, scale, shift, mean, invstd, R, a.C, act, parts, nparts, stream));
             } else if (pooled) {
                 PCB_TRY(op.max_bwd_reduce(dout, argmax, a.y, scale, shift, mean, invstd, R / pool, pool, a.C, act, bsums,
-                                          stream));
+                                          1, stream));
             } else {
-                PCB_TRY(op.bwd_reduce(dz, a.y, scale, shift, mean, invstd, R, a.C, act, bsums, stream));
+                PCB_TRY(op.bwd_reduce(dz, a.y, scale, shift, mean, invstd, R, a.C, act, bsums, 1, stream));
             }
             const float *gsums = nullptr;
             long rows = R;

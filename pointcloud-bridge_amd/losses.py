@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+
 # (class, classes that must lie below it, classes that must lie above it) -- models/model.py:176-182
 _ORDER = ((1, (), (2, 3, 4)), (2, (1,), (3, 4)), (3, (1, 2), (4,)), (4, (1, 2, 3), ()))
 
@@ -65,3 +67,64 @@ class BridgeStructureLoss(nn.Module):
             class_weights = class_weights * class_weights.new_tensor([1.0, 2.0, 1.0, 1.0, 2.0])  # :255-256
             w = weights.mean(dim=0) * class_weights
         return F.cross_entropy(logits.reshape(-1, 5), labels.reshape(-1), weight=w, label_smoothing=0.2)
+
+
+class _CrossEntropyRows(torch.autograd.Function):
+    """Mean cross entropy over logits rows [R, C] fp32 (`ld` floats apart) against labels [R] -- csrc/loss.hip:
+    one pass forward, one backward, instead of ATen's layout copy + log-softmax + nll_loss2d + fills."""
+
+    @staticmethod
+    def forward(ctx, rows, labels, ignore_index):
+        from .ops import _launch, on_device
+        R, C = rows.shape
+        dev = rows.device
+        lib = _lib.load()
+        partials = torch.empty(2 * lib.pcb_cross_entropy_partials(R), dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        with on_device(dev):
+            _launch("pcb_cross_entropy_fwd", R * C, rows.data_ptr(), rows.stride(0), labels.data_ptr(), R, C,
+                    int(ignore_index), partials.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(rows, labels, out)
+        ctx.ignore_index = int(ignore_index)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import _launch, on_device
+        rows, labels, out = ctx.saved_tensors
+        R, C = rows.shape
+        d = torch.empty(R, C, dtype=torch.float32, device=rows.device)
+        g = g.to(torch.float32).contiguous()
+        with on_device(rows.device):
+            _launch("pcb_cross_entropy_bwd", R * C, rows.data_ptr(), rows.stride(0), labels.data_ptr(), R, C,
+                    ctx.ignore_index, out.data_ptr(), g.data_ptr(), d.data_ptr())
+        return d, None, None
+
+
+def _as_rows(logits, channels_last):
+    """The [R, C] fp32 row view behind the logits if they ARE rows in memory (what the networks of this package
+    return: `rows.view(B, N, C).transpose(1, 2)` for the PointNet++ family, [B, N, C] for DGCNN); else None."""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() in (2, 3)):
+        return None
+    x = logits if (channels_last or logits.dim() == 2) else logits.transpose(1, 2)  # -> [B, N, C]
+    C = x.shape[-1]
+    if C > 64 or x.stride(-1) != 1:
+        return None
+    if x.dim() == 3:
+        if x.stride(0) != x.shape[1] * x.stride(1):
+            return None
+        x = x.reshape(-1, C)  # a view of the rows (their gradient is then rows as well: no layout copy in backward)
+    return x if x.stride(0) >= C else None
+
+
+def cross_entropy(logits, labels, channels_last=False, ignore_index=-100):
+    """nn.CrossEntropyLoss()(logits, labels) as the reference's trainers call it -- logits [B,C,N] (or
+    [B,N,C] / [R,C] with channels_last), labels [B,N] / [R] int64 -- on the library's one-pass kernel when the
+    logits are GPU fp32 rows in memory; any other input (CPU tensors, other layouts or dtypes) goes to
+    F.cross_entropy, the reference's own call."""
+    rows = _as_rows(logits, channels_last)
+    if rows is None or labels.dtype != torch.int64 or labels.numel() != rows.shape[0]:
+        if channels_last and logits.dim() == 3:
+            return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=ignore_index)
+        return F.cross_entropy(logits, labels, ignore_index=ignore_index)
+    return _CrossEntropyRows.apply(rows, labels.reshape(-1).contiguous(), ignore_index)

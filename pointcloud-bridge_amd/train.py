@@ -15,9 +15,8 @@ the parts of their loops that touch the hot path, with the same hyper-parameters
     (accumulated with one bincount instead of the reference's per-point Python loop, :226-231)
 """
 import torch
-import torch.nn.functional as F
 
-from . import parallel
+from . import losses, parallel
 
 
 def synthetic_scenes(num_scenes, num_points, num_classes=5, seed=0, device="cpu"):
@@ -36,9 +35,7 @@ def synthetic_scenes(num_scenes, num_points, num_classes=5, seed=0, device="cpu"
 
 def segmentation_loss(logits, labels, channels_last=False):
     """CrossEntropy on [B,C,N] logits (PointNet++ family) or, channels_last, on [B,N,C] (DGCNN)."""
-    if channels_last:
-        return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))
-    return F.cross_entropy(logits, labels)
+    return losses.cross_entropy(logits, labels, channels_last)
 
 
 def predictions(logits, channels_last=False):

@@ -1,0 +1,104 @@
+"""GPU: kernels added in the second half of round 2.
+
+  * the one-pass cross entropy (csrc/loss.hip) against F.cross_entropy -- the call the reference's trainers make
+    (train_MulSca_PN2.py:161 on [B,C,N], train_DGCNN.py:177-197 on [B*N,C]) -- loss and gradient, both layouts,
+    ignored labels, a row stride wider than C
+  * the BatchNorm-backward sums of a stack's top layer in slab mode (one slab per workgroup, no atomics) against
+    the single-slab mode and an fp64 evaluation
+  * the slab sums of a weight gradient with few slabs of a large matrix (the one-element-per-lane path)
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("layout", ["bcn", "bnc", "rows"])
+@pytest.mark.parametrize("C", [5, 13])
+def test_cross_entropy_matches_torch(layout, C):
+    from pointcloud_bridge_amd.losses import cross_entropy
+    torch.manual_seed(3)
+    B, N = 3, 1500
+    rows = (torch.randn(B * N, C, device="cuda") * 3).requires_grad_(True)
+    ref_rows = rows.detach().clone().requires_grad_(True)
+    labels = torch.randint(0, C, (B, N), device="cuda")
+    labels[0, :17] = -100  # ignored points
+    if layout == "bcn":   # what the PointNet++ containers return: a transposed view of the rows
+        loss = cross_entropy(rows.view(B, N, C).transpose(1, 2), labels)
+        ref = F.cross_entropy(ref_rows.view(B, N, C).transpose(1, 2), labels)
+    elif layout == "bnc":  # DGCNN
+        loss = cross_entropy(rows.view(B, N, C), labels, channels_last=True)
+        ref = F.cross_entropy(ref_rows.view(B, N, C).reshape(-1, C), labels.reshape(-1))
+    else:
+        loss = cross_entropy(rows, labels.reshape(-1), channels_last=True)
+        ref = F.cross_entropy(ref_rows, labels.reshape(-1))
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    (loss * 1.7).backward()
+    (ref * 1.7).backward()
+    assert torch.allclose(rows.grad, ref_rows.grad, rtol=1e-5, atol=1e-9)
+    assert rows.grad[:17].abs().max() == 0  # ignored points get no gradient
+
+
+def test_cross_entropy_strided_rows_and_fallback():
+    """Logits that are a column slice of wider rows are read in place; CPU logits take the reference's own call."""
+    from pointcloud_bridge_amd.losses import cross_entropy
+    torch.manual_seed(4)
+    wide = torch.randn(4096, 8, device="cuda")
+    labels = torch.randint(0, 5, (4096,), device="cuda")
+    got = cross_entropy(wide[:, :5], labels, channels_last=True)
+    ref = F.cross_entropy(wide[:, :5].contiguous(), labels)
+    assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref))
+    cpu = cross_entropy(wide[:, :5].cpu(), labels.cpu(), channels_last=True)
+    assert abs(float(cpu) - float(ref)) <= 1e-5 * abs(float(ref))
+
+
+@pytest.mark.parametrize("sfx,dtype", [("bf16", torch.bfloat16), ("f32", torch.float32)])
+@pytest.mark.parametrize("R,C", [(50000, 128), (8192, 1536), (333, 64)])
+def test_bwd_reduce_slabs(sfx, dtype, R, C):
+    from pointcloud_bridge_amd import _lib
+    if dtype == torch.float32 and C > 1024:
+        C = 1024  # one lane per 16-byte vector of a row: 256 vectors = 1024 fp32 / 2048 bf16 columns at most
+    lib = _lib.load()
+    torch.manual_seed(5)
+    dz = torch.randn(R, C, device="cuda").to(dtype)
+    y = torch.randn(R, C, device="cuda").to(dtype)
+    scale, shift = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.3
+    mean, invstd = torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.5
+    fn = getattr(lib, "pcb_bn_act_bwd_reduce_" + sfx)
+    du = dz.double() * ((y.double() * scale.double() + shift.double()) > 0)
+    want = torch.stack([du.sum(0), (du * (y.double() - mean.double()) * invstd.double()).sum(0)])
+    tol = 2e-3 * float(want.abs().max()) if dtype == torch.float32 else 2e-3 * float(want.abs().max())
+    for nparts in (1, 7, 768):
+        sums = torch.zeros(nparts, 2, C, device="cuda") if nparts == 1 else torch.full((nparts, 2, C), 7.0, device="cuda")
+        rc = fn(dz.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                R, C, 1, sums.data_ptr(), nparts, _stream())
+        assert rc == 0
+        got = sums.double().sum(0)
+        assert float((got - want).abs().max()) <= tol, (nparts, float((got - want).abs().max()), tol)
+    assert fn(dz.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+              R, C, 1, sums.data_ptr(), 769, _stream()) < 0  # more slabs than the library ever writes
+
+
+@pytest.mark.parametrize("R,M,N", [(8192, 1536, 1024), (262144, 64, 64)])
+def test_weight_gradient_slab_sums(R, M, N):
+    """dW = dy^T x through pcb_gemm_tn_bf16: few slabs of a large matrix (first shape) and hundreds of slabs of a
+    small one (second) take different paths of the slab-sum kernel; both against an fp64 product."""
+    from pointcloud_bridge_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(6)
+    dy = (torch.randn(R, M, device="cuda") * 0.1).to(torch.bfloat16)
+    x = (torch.randn(R, N, device="cuda") * 0.1).to(torch.bfloat16)
+    ws = torch.empty(lib.pcb_gemm_tn_workspace(R, M, N), dtype=torch.float32, device="cuda")
+    dW = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    rc = lib.pcb_gemm_tn_bf16(0, dy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(), 0, 0, 0, R, M, N,
+                              ws.data_ptr(), dW.data_ptr(), N, 0, _stream())
+    assert rc == 0
+    want = dy.double().t() @ x.double()
+    assert float((dW.double() - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-4

@@ -38,7 +38,7 @@ for R in (4096, 8192, 8192 + 64):
         mean, invstd = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
         sums = torch.zeros(2, C, device=dev)
         rc = lib.pcb_bn_act_bwd_reduce_f32(dz.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                                           invstd.data_ptr(), R, C, 1, sums.data_ptr(), st)
+                                           invstd.data_ptr(), R, C, 1, sums.data_ptr(), 1, st)
         torch.cuda.synchronize()
         du = dz.double() * ((y.double() * scale.double() + shift.double()) > 0)
         s1, s2 = du.sum(0), (du * (y.double() - mean.double()) * invstd.double()).sum(0)
