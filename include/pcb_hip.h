@@ -701,6 +701,11 @@ int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *
                         const int64_t *idx, int B, int N, int S, int ns, int C, const float *xyz,
                         const float *ctr, float *du, float *dv, float *dwx, void *stream);
 
+/* Raw fp32 input columns x [R, k] (rows `ld` floats apart: coordinates, colours) as a zero-padded operand
+ * out [R, kp] of the row type (kp a multiple of 8 for bf16, 4 for fp32): cast + pad in one pass. */
+int pcb_pad_rows_bf16(const float *x, long ld, long R, int k, int kp, void *out, void *stream);
+int pcb_pad_rows_f32(const float *x, long ld, long R, int k, int kp, void *out, void *stream);
+
 /*
  * Per-point cross entropy of the segmentation trainers (`criterion = nn.CrossEntropyLoss()` on [B,C,N]
  * logits vs [B,N] labels, train_MulSca_PN2.py:161; on [B*N,C] in train_DGCNN.py:177-197), mean over the

@@ -115,6 +115,8 @@ SIGNATURES = {
     "pcb_bn_act_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _i, _p],
     "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _i, _p],
     "pcb_bn_act_max_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _i, _p],
+    "pcb_pad_rows_bf16": [_p, _l, _l, _i, _i, _p, _p],
+    "pcb_pad_rows_f32": [_p, _l, _l, _i, _i, _p, _p],
     "pcb_cross_entropy_partials": [_l],
     "pcb_cross_entropy_fwd": [_p, _l, _p, _l, _i, _l, _p, _p, _p],
     "pcb_cross_entropy_bwd": [_p, _l, _p, _l, _i, _l, _p, _p, _p, _p],

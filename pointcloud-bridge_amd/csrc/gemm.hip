@@ -25,6 +25,7 @@
 // accumulation in v_mfma_f32_32x32x16_bf16, and no intermediate tensor.  gemm_tn needs both
 // operands transposed (reduction index = row = slow memory axis): tiles are stored row-major as
 // loaded and read back with ds_read_b64_tr_b16 (hardware transpose read).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "gemm_shared.h"
@@ -1049,6 +1050,8 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
                int out_cols, int out_perm, hipStream_t st, float *colsum = nullptr)
 {
     long rps;
+    static const bool trace = getenv("PCB_TN_TRACE") != nullptr;  // launch list for tools/tn_bench.py
+    if (trace) fprintf(stderr, "[pcb_tn] %d %d %ld %d %d %d\n", APRO, bpro, R, M, N, colsum ? 1 : 0);
     // fewer splits while another kernel holds CUs (never more than pcb_gemm_tn_workspace assumed)
     const long splits = pcb_tn_splits(R, M, N, &rps, 512 - 2 * pcb_busy_cus());
     const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;

@@ -122,10 +122,17 @@ thread_local int g_npending = -1;  // < 0: every reduction runs right behind its
 
 int launch_reduce_batch(const ReduceBatch &batch, int n, hipStream_t st)
 {
-    long most = 0;
-    for (int i = 0; i < n; ++i) most = batch.e[i].elems + batch.e[i].vlen > most ? batch.e[i].elems + batch.e[i].vlen : most;
-    long blocks = (most + 63) / 64;
-    if (blocks > 2048) blocks = 2048;
+    // workgroups an entry can use: few slabs -> 1024 elements per workgroup and step (at most 2048 of them),
+    // many slabs -> 64-element chunks walked by at most 1024 workgroups; the grid serves the neediest entry,
+    // the others' surplus workgroups leave at once
+    long blocks = 1;
+    for (int i = 0; i < n; ++i) {
+        const long total = batch.e[i].elems + batch.e[i].vlen;
+        long b = batch.e[i].splits <= 16 ? (total + 1023) / 1024 : (total + 63) / 64;
+        const long cap = batch.e[i].splits <= 16 ? 2048 : 1024;
+        b = b > cap ? cap : b;
+        blocks = b > blocks ? b : blocks;
+    }
     hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(1024), 0, st, batch);
     return pcb_check_launch();
 }
@@ -284,7 +291,7 @@ int prep_weights(int n, const long long *desc, float *zero, long zero_n, void *s
         if (a.l[i].C * a.l[i].kp > most) most = a.l[i].C * a.l[i].kp;
     }
     int gx = (most + 255) / 256;
-    if (gx > 256) gx = 256;
+    if (gx > 2048) gx = 2048;  // (256 made the 1536 x 1024 layers of the bottleneck levels a 21 us launch: 24 scattered 2-byte writes of W^T per lane)
     hipLaunchKernelGGL(prep_weights_kernel<T>, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
     return pcb_check_launch();
 }
@@ -315,7 +322,7 @@ int prep_linear_bias(const float *w, const float *bias, int n, int k, int npad, 
 {
     if (!w || !wp || !bp || n <= 0 || k <= 0 || npad < n || kp < k || gap < 0) return PCB_ERR_INVALID_ARG;
     const int blocks = (npad * kp + 255) / 256;
-    hipLaunchKernelGGL(prep_linear_bias_kernel<T>, dim3(blocks < 64 ? blocks : 64), dim3(256), 0, (hipStream_t)stream, w,
+    hipLaunchKernelGGL(prep_linear_bias_kernel<T>, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, (hipStream_t)stream, w,
                        bias, n, k, npad, kp, gap, (T *)wp, (T *)wt, bp);
     return pcb_check_launch();
 }
@@ -342,6 +349,26 @@ int pcb_zero_async(void *ptr, size_t bytes, hipStream_t st)
     size_t blocks = ((words >> 2) + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)ptr, words);
+    return pcb_check_launch();
+}
+
+// two buffers cleared by one launch (the du and dWx accumulators of a gathered layer's backward pass)
+static __global__ __launch_bounds__(256) void zero2_kernel(uint32_t *__restrict__ a, size_t wa, uint32_t *__restrict__ b, size_t wb)
+{
+    const size_t va = wa >> 2;   // a: 16-byte stores (the large one), tail and b word by word
+    uint4 *__restrict__ a4 = reinterpret_cast<uint4 *>(a);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < va; i += (size_t)gridDim.x * 256) a4[i] = make_uint4(0, 0, 0, 0);
+    for (size_t i = (va << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < wa; i += (size_t)gridDim.x * 256) a[i] = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < wb; i += (size_t)gridDim.x * 256) b[i] = 0u;
+}
+int pcb_zero2_async(void *a, size_t bytes_a, void *b, size_t bytes_b, hipStream_t st)
+{
+    if (!b || !bytes_b) return pcb_zero_async(a, bytes_a, st);
+    if (!a || (bytes_a & 3) || (bytes_b & 3) || ((uintptr_t)a & 15)) return PCB_ERR_INVALID_ARG;
+    const size_t wa = bytes_a >> 2, wb = bytes_b >> 2;
+    size_t blocks = (((wa >> 2) > wb ? (wa >> 2) : wb) + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(zero2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)a, wa, (uint32_t *)b, wb);
     return pcb_check_launch();
 }
 

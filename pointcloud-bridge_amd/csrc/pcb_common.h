@@ -100,6 +100,7 @@ int pcb_defer_reduces_flush(hipStream_t st);
 // once anything ran between replays; tools/graph_reduce_repro.py).  bytes must be a multiple of 4.
 int pcb_zero_async(void *ptr, size_t bytes, hipStream_t st);
 int pcb_copy_async(void *dst, const void *src, size_t bytes, hipStream_t st);
+int pcb_zero2_async(void *a, size_t bytes_a, void *b, size_t bytes_b, hipStream_t st);  // b may be NULL
 
 static inline int pcb_check_launch()
 {

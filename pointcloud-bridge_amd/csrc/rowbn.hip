@@ -507,6 +507,24 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(const uint4 *__restr
     }
 }
 
+// Raw fp32 input columns (coordinates, colours: [R, k] with k = 3) as a zero-padded GEMM operand [R, kp] of
+// the row type: cast + pad in one pass (ATen: a cast, a zero fill and a strided copy).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pad_rows_kernel(const float *__restrict__ x, long ld, int k, int kp,
+                                                             T *__restrict__ out, long nvec)
+{
+    constexpr int E = RowVec<T>::E;
+    const int KT = kp / E;
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < nvec; e += (long)gridDim.x * kThreads) {
+        const long r = e / KT;
+        const int j0 = (int)(e - r * KT) * E;
+        float f[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) f[i] = j0 + i < k ? x[r * ld + j0 + i] : 0.0f;
+        *reinterpret_cast<uint4 *>(out + r * (long)kp + j0) = RowVec<T>::pack(f);
+    }
+}
+
 inline int grid_for(long work, int per_block = kThreads, int cap = 4096)
 {
     long blocks = (work + per_block - 1) / per_block;
@@ -661,6 +679,18 @@ int group_rows_bwd(const void *grad_rows, const int64_t *idx, int B, int N, int 
 }
 
 template <typename T>
+int pad_rows(const float *x, long ld, long R, int k, int kp, void *out, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (!x || !out || R <= 0 || k <= 0 || kp < k || (kp % E) || ld < k) return PCB_ERR_INVALID_ARG;
+    const long nvec = R * (kp / E);
+    hipLaunchKernelGGL(pad_rows_kernel<T>, dim3(grid_for(nvec)), dim3(kThreads), 0, (hipStream_t)stream, x, ld, k, kp,
+                       (T *)out, nvec);
+    pcb_account(4.0 * R * k + (double)sizeof(T) * R * kp);
+    return pcb_check_launch();
+}
+
+template <typename T>
 int gate(const void *x, const void *a, void *out, long n, void *stream)
 {
     constexpr int E = RowVec<T>::E;
@@ -802,6 +832,9 @@ int pcb_bn_act_max_bwd_reduce_f32(const float *dout, const unsigned char *argmax
 {
     return bn_act_max_bwd_reduce<float>(dout, argmax, y, scale, shift, mean, invstd, groups, ns, C, act, sums, nparts, stream);
 }
+
+int pcb_pad_rows_bf16(const float *x, long ld, long R, int k, int kp, void *out, void *stream) { return pad_rows<pcb_bf16>(x, ld, R, k, kp, out, stream); }
+int pcb_pad_rows_f32(const float *x, long ld, long R, int k, int kp, void *out, void *stream) { return pad_rows<float>(x, ld, R, k, kp, out, stream); }
 
 int pcb_gate_bf16(const void *x, const void *a, void *out, long n, void *stream) { return gate<pcb_bf16>(x, a, out, n, stream); }
 int pcb_gate_f32(const void *x, const void *a, void *out, long n, void *stream) { return gate<float>(x, a, out, n, stream); }

@@ -567,9 +567,8 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
             if (gathered && l == 0) {
                 // gathered layer: its input gradients are du (per source point) and dv (per centroid)
                 if (pooled && pool != ga.ns) return PCB_ERR_INVALID_ARG;
-                if (pcb_zero_async(ga.u, sizeof(float) * (size_t)ga.B * ga.N * a.C, main_st) != PCB_OK)
-                    return PCB_ERR_LAUNCH;
-                if (ga.wx && pcb_zero_async(ga.wx, sizeof(float) * 3 * a.C * 33, main_st) != PCB_OK)
+                if (pcb_zero2_async(ga.u, sizeof(float) * (size_t)ga.B * ga.N * a.C, ga.wx, sizeof(float) * 3 * a.C * 33,
+                                    main_st) != PCB_OK)
                     return PCB_ERR_LAUNCH;
                 PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx,
                                             ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.u, ga.v, ga.wx, stream));

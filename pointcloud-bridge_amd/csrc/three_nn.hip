@@ -226,17 +226,22 @@ __global__ __launch_bounds__(256) void interpolate_rows_kernel(const T *__restri
         const long b = row / N;
         float w[K];
         float norm = 0.0f;
+        // fp32 rows: correctly rounded divisions, the reference's `1.0 / (dists + 1e-8)` and `/ norm` (:196-198).
+        // bf16 rows: the hardware reciprocal (1 ulp) -- the 2K IEEE divisions, repeated by every lane of a row, were
+        // a third of this kernel's instructions, and the products are rounded to bf16 anyway.
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            w[k] = __fdiv_rn(1.0f, __fadd_rn(d2[row * K + k], 1e-8f));
+            const float d = __fadd_rn(d2[row * K + k], 1e-8f);
+            w[k] = E == 4 ? __fdiv_rn(1.0f, d) : __builtin_amdgcn_rcpf(d);
             norm = k ? __fadd_rn(norm, w[k]) : w[k];
         }
+        const float rnorm = E == 4 ? 0.0f : __builtin_amdgcn_rcpf(norm);
         float acc[E];
 #pragma unroll
         for (int i = 0; i < E; ++i) acc[i] = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            w[k] = __fdiv_rn(w[k], norm);
+            w[k] = E == 4 ? __fdiv_rn(w[k], norm) : w[k] * rnorm;
             const int j = clamp_index(idx[row * K + k], S);
             float f[E];
             RowVec<T>::unpack(*reinterpret_cast<const uint4 *>(feat + ((b * S + j) * (long)C + cc * E)), f);

@@ -151,6 +151,14 @@ def _bn_bookkeeping(bn):
 
 def _rows(x, kp, m):
     """Make x [R,K] a contiguous [R,kp] operand of row type m (zero padded on the right)."""
+    if (x.dtype == torch.float32 and x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] < kp
+            and not (x.requires_grad and torch.is_grad_enabled())):
+        # raw input columns (coordinates, colours): cast + pad in one launch instead of three
+        out = torch.empty(x.shape[0], kp, dtype=m.dtype, device=x.device)
+        with on_device(x.device):
+            _launch("pcb_pad_rows_" + m.sfx, x.shape[0] * kp, x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], kp,
+                    out.data_ptr())
+        return out
     x = x.to(m.dtype)
     if x.shape[1] == kp:
         return x.contiguous()

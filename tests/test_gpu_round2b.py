@@ -102,3 +102,17 @@ def test_weight_gradient_slab_sums(R, M, N):
     assert rc == 0
     want = dy.double().t() @ x.double()
     assert float((dW.double() - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("sfx,dtype,kp", [("bf16", torch.bfloat16, 8), ("f32", torch.float32, 4)])
+def test_pad_rows(sfx, dtype, kp):
+    """Raw fp32 coordinate / colour columns as a padded operand of the row type: equal to cast + F.pad."""
+    from pointcloud_bridge_amd import rowmlp
+    x = torch.randn(5000, 6, device="cuda")[:, :3]  # rows 6 floats apart
+    rowmlp.set_precision("bf16" if sfx == "bf16" else "fp32")
+    try:
+        got = rowmlp._rows(x, kp, rowmlp.mode())
+    finally:
+        rowmlp.set_precision("fp32")
+    want = F.pad(x.to(dtype), (0, kp - 3))
+    assert got.dtype == dtype and torch.equal(got, want)
