@@ -1029,7 +1029,8 @@ void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, 
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)(sums ? nparts : pcb_nt_grid_x(PRO, R, N, pcb_busy_cus())), ny);
     RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
-    if (PRO <= PRO_BNACT && K <= N8_MAXK) {
+    // the eight-wave form: its LDS constants limit K for the BatchNorm-on-load prologue only (plain rows: any K)
+    if (PRO == PRO_PLAIN || (PRO == PRO_BNACT && K <= N8_MAXK)) {
         // forward prologues: the eight-wave form, two workgroups per CU
         if (sums)
             hipLaunchKernelGGL((gemm_nt8_kernel<PRO, 1, 0, 4, 4>), grid, dim3(512), 0, st, A, Bw, R, N, K, out, sums, none);
@@ -1180,12 +1181,8 @@ extern "C" int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);
-    if (K <= N8_MAXK)
-        hipLaunchKernelGGL((gemm_nt8_kernel<PRO_PLAIN, 0, 0, 4, 4>), grid, dim3(512), 0, st, A, (const u16 *)w, R, N, K,
-                           (u16 *)out, (float *)nullptr, epi);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<PRO_PLAIN, 0, 0>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out,
-                           (float *)nullptr, epi);
+    hipLaunchKernelGGL((gemm_nt8_kernel<PRO_PLAIN, 0, 0, 4, 4>), grid, dim3(512), 0, st, A, (const u16 *)w, R, N, K,
+                       (u16 *)out, (float *)nullptr, epi);
     pcb_timer_end(st, timed, nt_bytes(PRO_PLAIN, R, N, K, 0), PRO_PLAIN, R, N, K);
     return pcb_check_launch();
 }
