@@ -149,6 +149,7 @@ class Run:
         from pointcloud_bridge_amd.models import pointnet2_utils as pu
         self.args, self.model_name, self.precision, self.mode, self.family = args, model_name, precision, mode, family
         self.B, self.N, self.rank, self.world, self.device = B, N, rank, world, device
+        self.coll = parallel.collectives()   # world > 1, or the one-rank RCCL rehearsal (PCB_DIST_SINGLE=1)
         rowmlp.set_precision(precision)
         torch.manual_seed(42)  # identical init on every rank; broadcast below makes it certain
         model, self.cdim = build_model(model_name)
@@ -318,7 +319,7 @@ class Run:
     # -- the timed loop ---------------------------------------------------------------------------
     def fence(self):
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -370,7 +371,7 @@ class Run:
             self.fence()
             dt = min(dt, (time.perf_counter() - t0) / steps)
         gc.enable()
-        if self.world > 1:
+        if self.coll:
             t = torch.tensor([dt], dtype=torch.float64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -405,7 +406,7 @@ class Run:
             host_s += time.perf_counter() - h0
             if self.args.dump:
                 lg = loss.detach().clone()
-                if self.world > 1:  # the mean over ALL scenes, as a single process would report it
+                if self.coll:  # the mean over ALL scenes, as a single process would report it
                     dist.all_reduce(lg, op=dist.ReduceOp.SUM)
                     lg /= self.world
                 losses.append(lg)
@@ -415,7 +416,7 @@ class Run:
         launches, kernel_ms, nt_bytes = ops.kernel_timer_stop()
         fps_n, fps_ms, _ = ops.kernel_timer_read(1)
         all_n, _, all_bytes = ops.kernel_timer_read(-1)
-        if self.world > 1:
+        if self.coll:
             t = torch.tensor([dt], dtype=torch.float64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -522,7 +523,7 @@ def main():
         except Exception as e:  # a capture that fails must not cost the run
             ok = 0
             probes["graph_error"] = f"{type(e).__name__}: {e}"[:200]
-        if world > 1:
+        if parallel.collectives():
             # the two modes exchange gradients differently (buckets vs one flat all-reduce): every rank must take
             # the same one, so a capture that failed anywhere sends all ranks to the eager step
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
@@ -646,7 +647,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, N)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if parallel.collectives():
         dist.barrier()
         dist.destroy_process_group()
 

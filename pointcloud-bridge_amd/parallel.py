@@ -21,7 +21,7 @@ def init_from_env(backend=None):
 
     Returns (rank, world_size, local_rank).  Single-process runs return (0, 1, 0) untouched."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not (os.environ.get("PCB_DIST_SINGLE") == "1" and "RANK" in os.environ):
         return 0, 1, 0
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -36,6 +36,16 @@ def init_from_env(backend=None):
             kw["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def collectives(group=None):
+    """True where the gradient exchange really calls the process group: more than one rank -- or a one-rank
+    group under PCB_DIST_SINGLE=1, the rehearsal of the RCCL path on a one-GPU box (torch.distributed.run
+    --nproc-per-node 1: communicator, streams, barriers and the captured step beside RCCL's watchdog thread are
+    the real ones, only the peers are missing)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("PCB_DIST_SINGLE") == "1"
 
 
 def shard_scenes(num_scenes, rank, world):
@@ -64,6 +74,7 @@ class FlatGradAllReduce:
         # per-parameter .grad tensors are left as they are (NOT averaged)
         self.assign_views = assign_views
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.coll = collectives(group)
         self.flat = None
         for p in self.params:
             if p.dtype != torch.float32:
@@ -82,7 +93,7 @@ class FlatGradAllReduce:
         """Sum over ranks, divide by the world size (mean, as DDP does).  With one rank: .flat is just
         the packed gradient (no collective), so callers need no special case."""
         self.flat = self.pack()
-        if self.world == 1:
+        if not self.coll:
             return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(self.world)
@@ -135,6 +146,7 @@ class OverlappedGradAllReduce:
             raise TypeError("OverlappedGradAllReduce expects fp32 master parameters")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.coll = collectives(group)
         dev = self.params[0].device
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         index = {id(p): i for i, p in enumerate(self.params)}
@@ -206,7 +218,7 @@ class OverlappedGradAllReduce:
                    for i in members], out=self.flat[lo:hi])
         for i in members:
             self.params[i].grad = None  # the flat buffer is the gradient from here on
-        if self.world > 1:
+        if self.coll:
             self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def zero(self):
@@ -290,7 +302,7 @@ class FlatAdam:
 
 def broadcast_parameters(module, src=0, group=None):
     """Make every rank start from rank `src`'s parameters and buffers."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives(group):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)

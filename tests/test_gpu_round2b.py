@@ -116,3 +116,43 @@ def test_pad_rows(sfx, dtype, kp):
         rowmlp.set_precision("fp32")
     want = F.pad(x.to(dtype), (0, kp - 3))
     assert got.dtype == dtype and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_bench_on_a_one_rank_rccl_group(tmp_path, mode):
+    """The gradient exchange on the REAL backend (`nccl` = RCCL) with one rank -- all this box can host:
+    torch.distributed.run --nproc-per-node 1, PCB_DIST_SINGLE=1 makes bench.py join the group and issue every
+    collective of the multi-GPU run (parameter broadcast, bucketed asynchronous all-reduce during the backward pass
+    or the flat one behind the captured step, the barriers and max-reductions of the timing, the mode vote).  The
+    losses equal those of the plain single-process run: a sum over one rank changes nothing."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PCB_DIST_BACKEND", None)
+    common = ["--gpus", "1", "--steps", "3", "--warmup", "0" if mode == "eager" else "2", "--npoints", "2048", "--batch", "4",
+              "--no-cpu-baseline", "--no-extras", "--no-dropout", "--exec", mode]
+    if mode == "eager":
+        common += ["--precision", "fp32"]  # two runs of the same fp32 command agree to ~2e-6 (tools/grad_noise.py); bf16 rows: 8e-3
+    dumps = (str(tmp_path / "plain.pt"), str(tmp_path / "rccl.pt"))
+    extra = (lambda i: ["--dump", dumps[i]]) if mode == "eager" else (lambda i: [])  # (a dump keeps the step eager)
+    plain = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + common + extra(0), env=env,
+                           capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-4000:]
+    port = "29683" if mode == "eager" else "29684"
+    rccl = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(repo, "bench.py")] + common
+                          + extra(1), env=dict(env, PCB_DIST_SINGLE="1"), capture_output=True, text=True, timeout=600)
+    assert rccl.returncode == 0, rccl.stdout[-2000:] + rccl.stderr[-4000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(rccl.stdout.strip().splitlines()[-1])
+    assert b["config"]["exec"]["mode"] == mode
+    # (bf16 rows, scatter-adds by fp32 atomics: two runs of the SAME command differ by ~5e-4 after five Adam steps)
+    assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-2 * abs(a["config"]["loss"]), (a["config"]["loss"], b["config"]["loss"])
+    if mode == "eager":
+        da, db = torch.load(dumps[0], weights_only=True), torch.load(dumps[1], weights_only=True)
+        assert abs(da["losses"][0] - db["losses"][0]) <= 1e-6 * abs(da["losses"][0])  # the first forward pass: no update yet
+        ga, gb = da["first_grad"], db["first_grad"]
+        assert float((ga - gb).norm() / ga.norm()) < 1e-4  # the all-reduced gradient IS the local one
