@@ -477,6 +477,12 @@ int pcb_prep_weights_f32(int n, const long long *desc, void *stream);
 int pcb_prep_weights_zero_bf16(int n, const long long *desc, float *zero, long zero_n, void *stream);
 int pcb_prep_weights_zero_f32(int n, const long long *desc, float *zero, long zero_n, void *stream);
 
+/* The dy = scale*du + p*y + q of pcb_gemm_nt_bf16's prologue 2 written out as bf16 rows [R,C] (C <= 2048): for
+ * layers whose gradient GEMMs would rebuild it once per column tile of a wide partner matrix (used by
+ * pcb_mlp_stack_backward where C > 256 and the layer has more than 256 inputs). */
+int pcb_dy_rows_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *p,
+                     const float *q, int act, long R, int C, void *dy, void *stream);
+
 /* pcb_gemm_nt_* (pro 2 or 3, N <= 128) whose epilogue also accumulates the BatchNorm-backward
  * sums of the layer BELOW: the produced tile is that layer's dz; with its y (red_y [R,N]) and
  * constants, (sum du, sum du*xhat) go to red_sums = [nparts][2][N] slabs (nparts as above).
@@ -648,7 +654,9 @@ int pcb_attention_fwd_bf16(const void *qkv, int B, int N, int H, int D, float sc
  * preparation and the per-layer BatchNorm finalize are skipped (inference with constant weights).
  * Backward only: g = dz [R,C_last] (pool 0) or dout fp32 [R/ns,C_last]; workspace fp32, >= the
  * SUM of pcb_gemm_tn_workspace(R,C_l,Kp_l) over the layers that have a dW (each keeps its slabs until
- * one launch at the end of the pass sums them all); dzbuf [2][R][max(8, Kp, widths of all but the last layer)] (L > 1); dx [R,Kp] or NULL.
+ * one launch at the end of the pass sums them all); dzbuf: pcb_mlp_stack_dzbuf_elems(...) elements of the row type (two
+ * gradient slots [R][max(8, Kp, inner widths)], wider where a top layer's dy is written out once; 0 = not needed: NULL);
+ * dx [R,Kp] or NULL.
  */
 #define PCB_STACK_MAX_LAYERS 16
 typedef struct pcb_sync {
@@ -657,6 +665,7 @@ typedef struct pcb_sync {
     long global_rows;
 } pcb_sync;
 long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, int need_wt0);
+long pcb_mlp_stack_dzbuf_elems(int dtype, int L, const long long *desc, long R, int Kp, int pool, int gathered);
 int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, const double *fdesc, const void *x, long R,
                           int Kp, int perm, int act, int pool, int need_wt0, int stat_repeat,
                           const long long *gather, void *wbuf, float *stz, float *parts, int parts_slabs,

@@ -115,6 +115,8 @@ SIGNATURES = {
     "pcb_bn_act_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _i, _p],
     "pcb_bn_act_max_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _i, _p],
     "pcb_bn_act_max_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _i, _p],
+    "pcb_mlp_stack_dzbuf_elems": [_i, _i, _p, _l, _i, _i, _i],
+    "pcb_dy_rows_bf16": [_p, _p, _p, _p, _p, _p, _i, _l, _i, _p, _p],
     "pcb_pad_rows_bf16": [_p, _l, _l, _i, _i, _p, _p],
     "pcb_pad_rows_f32": [_p, _l, _l, _i, _i, _p, _p],
     "pcb_cross_entropy_partials": [_l],
@@ -143,7 +145,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the build lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "pcb_status_string"
-                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems", "pcb_knn_xyz_workspace",
+                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems", "pcb_mlp_stack_dzbuf_elems", "pcb_knn_xyz_workspace",
                                                      "pcb_scene_max_workspace", "pcb_scene_colsum_workspace")
                           else ctypes.c_int)
         _lib = lib

@@ -1020,6 +1020,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     }
 }
 
+// dy = scale*du + p*y + q written out as rows (the PRO_DY prologue as a pass of its own), for the layers whose
+// gradient GEMMs would otherwise rebuild it once per 128-column tile of a WIDE partner matrix: the input-gradient
+// GEMM of a layer with K = C > 256 (too wide for the A-resident kernel) and N > 256 inputs walks >= 3 column tiles,
+// the weight-gradient GEMM as many tiles again (R = 8192, C = 1024, 1536 inputs: 12 + 12 times).  One lane owns a
+// 16-byte column chunk (its constants stay in registers) and walks rows.
+__global__ __launch_bounds__(256) void dy_rows_kernel(Operand A_arg, long R, int C, u16 *__restrict__ out)
+{
+    const Operand A = local_copy(A_arg);
+    const float slope = act_slope(A.act);
+    const int CT = C / 8, RT = 256 / CT;
+    const int cc = threadIdx.x % CT, rl = threadIdx.x / CT;
+    if (rl >= RT) return;
+    Consts<PRO_DY> k;
+    k.load(A, cc * 8, C);
+    const long step = (long)gridDim.x * RT;
+    for (long r0 = (long)blockIdx.x * RT + rl; r0 < R; r0 += 2 * step) {
+        Raw<PRO_DY> ra[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ra[u].load(A, r0 + u * step, cc * 8, R, C);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (r0 + u * step < R) *reinterpret_cast<uint4 *>(out + (r0 + u * step) * C + cc * 8) = ra[u].finish(k, slope);
+    }
+}
+
 template <int PRO>
 void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, float *sums, int nparts, hipStream_t st,
                const RedArgs *red = nullptr)
@@ -1147,6 +1172,20 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
         default: launch_nt<PRO_DY_POOL>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, nparts, st); break;
     }
     pcb_timer_end(st, timed, bytes, pro, R, N, K);
+    return pcb_check_launch();
+}
+
+extern "C" int pcb_dy_rows_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *p,
+                                const float *q, int act, long R, int C, void *dy, void *stream)
+{
+    if (!dz || !y || !scale || !shift || !p || !q || !dy || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(C) || C > 2048) return PCB_ERR_UNSUPPORTED;
+    const Operand A = make_operand(dz, y, C, scale, shift, p, q, nullptr, nullptr, 1, act);
+    const long RT = 256 / (C / 8);
+    long blocks = (R + RT * 4 - 1) / (RT * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(dy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, R, C, (u16 *)dy);
+    pcb_account(6.0 * R * C);
     return pcb_check_launch();
 }
 

@@ -334,6 +334,35 @@ extern "C" long pcb_mlp_stack_wbuf_elems(int L, const long long *desc, int Kp, i
 }
 
 namespace {
+// Layers whose dy is written out once (pcb_dy_rows_bf16) instead of being rebuilt in the prologues of their
+// gradient GEMMs: bf16 rows, dense dz, wider than the A-resident input-gradient kernel takes (C > 256) and
+// more than 256 inputs -- both GEMMs then walk >= 3 column tiles of the partner matrix.
+inline bool materialise_dy(int dtype, bool pooled, int C, int kp) { return dtype == PCB_DTYPE_BF16 && !pooled && C > 256 && C <= 2048 && kp > 256; }
+
+// row stride of the two gradient ping-pong slots: the widest dz they hold -- and the top layer's dy where that is
+// written out (slot L & 1 is free while layer L-1, which reads the caller's g, runs)
+inline int dz_stride(int dtype, int L, const Layer *ly, int Kp, int pool, bool gathered)
+{
+    int maxw = Kp > 8 ? Kp : 8;
+    for (int l = 0; l + 1 < L; ++l) maxw = ly[l].C > maxw ? ly[l].C : maxw;
+    const Layer &top = ly[L - 1];
+    if (!(gathered && L == 1) && materialise_dy(dtype, pool != 0, top.C, top.kp) && top.C > maxw) maxw = top.C;
+    return maxw;
+}
+}  // namespace
+
+extern "C" long pcb_mlp_stack_dzbuf_elems(int dtype, int L, const long long *desc, long R, int Kp, int pool, int gathered)
+{
+    Layer ly[PCB_STACK_MAX_LAYERS];
+    if (dtype != PCB_DTYPE_BF16 && dtype != PCB_DTYPE_F32) return 0;
+    if (parse(L, desc, gathered ? 0 : Kp, 1, gathered != 0, kOps[dtype].quantum, ly) != PCB_OK || R <= 0) return 0;
+    const Layer &top = ly[L - 1];
+    const bool top_mat = !(gathered && L == 1) && materialise_dy(dtype, pool != 0, top.C, top.kp);
+    if (L == 1 && !top_mat) return 0;
+    return 2L * R * dz_stride(dtype, L, ly, gathered ? 0 : Kp, pool, gathered != 0);
+}
+
+namespace {
 struct Gather {
     float *u, *v;  // forward: u, v (v optional);  backward: du, dv
     const int64_t *idx;
@@ -487,8 +516,7 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
     if (parts && parts_slabs < 1) return PCB_ERR_INVALID_ARG;
     if (sync && (!sync->allreduce || sync->global_rows < R || !parts)) return PCB_ERR_INVALID_ARG;
     const char *wb = (const char *)wbuf;
-    int maxw = Kp > 8 ? Kp : 8;
-    for (int l = 0; l + 1 < L; ++l) maxw = ly[l].C > maxw ? ly[l].C : maxw;
+    const int maxw = dz_stride(dtype, L, ly, Kp, pool, gathered);
     if (L > 1 && !dzbuf) return PCB_ERR_INVALID_ARG;
     const int busy = pcb_busy_cus();  // one reading of the hint for the whole call
 
@@ -562,8 +590,16 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
             PCB_TRY(pcb_bn_bwd_finalize(sums, nparts, rows, a.C, scale, mean, invstd, a.training, p, q, a.dgamma, a.dbeta,
                                         a.dbias, gsums, stream));
             have_parts = false;
-            const int apro = pooled ? 3 : 2;
+            int apro = pooled ? 3 : 2;
             const int ns = pooled ? pool : 1;
+            if (dzbuf && !(gathered && l == 0) && materialise_dy(dtype, pooled, a.C, a.kp) && (a.dW || l > 0 || dx)) {
+                // dy once, as rows: in place over this layer's dz where that is one of the ping-pong slots, in the
+                // free slot for the top layer (whose dz is the caller's tensor)
+                void *dyb = (l == L - 1) ? (void *)((char *)dzbuf + (size_t)(L & 1) * R * maxw * op.elem) : const_cast<void *>(dz);
+                PCB_TRY(pcb_dy_rows_bf16(dz, a.y, scale, shift, p, q, act, R, a.C, dyb, stream));
+                dz = dyb;
+                apro = 0;
+            }
             if (gathered && l == 0) {
                 // gathered layer: its input gradients are du (per source point) and dv (per centroid)
                 if (pooled && pool != ga.ns) return PCB_ERR_INVALID_ARG;

@@ -362,8 +362,9 @@ class _FusedStack(torch.autograd.Function):
         desc = _stack_desc(layers, widths, ybuf, R, m, outs)
         want_dx = bool(ctx.needs_input_grad[0]) and need_dx
         dx = torch.empty(R, Kp, dtype=m.dtype, device=dev) if want_dx else None
-        maxw = max([8, Kp] + widths[:-1])  # the library's ping-pong stride: max(8, Kp, inner widths)
-        dzbuf = torch.empty(2 * R * maxw, dtype=m.dtype, device=dev) if L > 1 else None
+        # the two gradient ping-pong slots (and, for a wide top layer, its dy written out once): sized by the library
+        nz = lib.pcb_mlp_stack_dzbuf_elems(m.code, L, desc, R, Kp, pool, 0)
+        dzbuf = torch.empty(nz, dtype=m.dtype, device=dev) if nz else None
         parts = torch.empty(_MAX_PARTS * 2 * max(widths + [Kp]), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
         sync = _Sync(group, R, (stz, parts)) if group is not False else None
@@ -554,7 +555,8 @@ class _GatheredStack(torch.autograd.Function):
             du.data_ptr(), 0 if dv is None else dv.data_ptr(), idx.data_ptr(), B, N, S, ns,
             0 if dwx is None else xyz.data_ptr(), 0 if dwx is None else ctr.data_ptr(),
             0 if dwx is None else dwx.data_ptr(), 3, 0)
-        dzbuf = torch.empty(2 * R * max([8] + widths[:-1]), dtype=torch.bfloat16, device=dev) if L > 1 else None
+        nz = lib.pcb_mlp_stack_dzbuf_elems(_MODES["bf16"].code, L, desc, R, 0, pool, 1)
+        dzbuf = torch.empty(nz, dtype=torch.bfloat16, device=dev) if nz else None
         parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
         ws = torch.empty(max(ws_elems, 1), dtype=torch.float32, device=dev)
         apply_concurrency_hint()

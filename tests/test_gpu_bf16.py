@@ -103,7 +103,9 @@ def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, R, K, C, act, pool):
 
 @pytest.mark.parametrize("R,K,widths,act,pool,perm", [(2048, 8, [64, 64, 128], 1, 16, 0), (1024, 264, [128, 128, 256], 1, 32, 0),
                                                       (3000, 72, [256, 128], 1, 0, 0), (1280, 128, [64], 2, 20, 0),
-                                                      (1536, 24, [32, 32, 64], 1, 8, 16), (1100, 264, [256, 256], 1, 0, 0)])
+                                                      (1536, 24, [32, 32, 64], 1, 8, 16), (1100, 264, [256, 256], 1, 0, 0),
+                                                      # dy written out once (C > 256 with > 256 inputs): top layer / inner layer / single layer
+                                                      (900, 384, [512, 320], 1, 0, 0), (700, 320, [384, 64], 1, 0, 0), (600, 264, [384], 2, 0, 0)])
 def test_fused_stack_forward_backward_vs_torch_fp32(rm, R, K, widths, act, pool, perm):
     """Multi-layer stack: BatchNorm+activation applied on operand load, statistics from the GEMM
     epilogue, dy recomputed on load in both backward GEMMs -- against a plain fp32 torch stack."""
