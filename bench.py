@@ -149,6 +149,7 @@ class Run:
         from pointcloud_bridge_amd.models import pointnet2_utils as pu
         self.args, self.model_name, self.precision, self.mode, self.family = args, model_name, precision, mode, family
         self.B, self.N, self.rank, self.world, self.device = B, N, rank, world, device
+        self.rowmlp = rowmlp
         self.coll = parallel.collectives()   # world > 1, or the one-rank RCCL rehearsal (PCB_DIST_SINGLE=1)
         rowmlp.set_precision(precision)
         torch.manual_seed(42)  # identical init on every rank; broadcast below makes it certain
@@ -220,6 +221,7 @@ class Run:
         if self.args.dump and self.i == 0:
             self.first_grad = flat.detach().clone()  # the averaged gradient of the first step (equivalence tests)
         self.opt.step(flat)
+        self.rowmlp.prepare_step()   # the operands of every stack from the new weights: one launch (rowmlp.prepare_step)
         self.i += 1
         return loss
 
@@ -254,6 +256,7 @@ class Run:
         loss_buf = torch.zeros((), device=self.device)
 
         def fwd_bwd():
+            self.rowmlp.prepare_step()           # operands of every stack from the weights the last Adam step left
             if static is not None:
                 static.commit()                  # what the previous step computed for this batch becomes live
             loss = self.loss_of(model(xyz, colors), batch)

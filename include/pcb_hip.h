@@ -473,6 +473,10 @@ int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *
  * -D < 0 = interpolate+concat rows (first D columns in place, the rest from column pad(D)). */
 int pcb_prep_weights_bf16(int n, const long long *desc, void *stream);
 int pcb_prep_weights_f32(int n, const long long *desc, void *stream);
+/* The same for any number of layers from a table in DEVICE memory (n rows of 8 int64 as above; max_elems = the
+ * largest C*kp among them): the operands of every stack of a network in one launch per optimiser step. */
+int pcb_prep_weights_table_bf16(const long long *table, int n, long max_elems, void *stream);
+int pcb_prep_weights_table_f32(const long long *table, int n, long max_elems, void *stream);
 /* The same, and `zero` [zero_n] fp32 is cleared by the same launch (a stack's constants buffer). */
 int pcb_prep_weights_zero_bf16(int n, const long long *desc, float *zero, long zero_n, void *stream);
 int pcb_prep_weights_zero_f32(int n, const long long *desc, float *zero, long zero_n, void *stream);
@@ -649,6 +653,8 @@ int pcb_attention_fwd_bf16(const void *qkv, int B, int N, int H, int D, float sc
  *   enqueue a SUM all-reduce of the n floats at device pointer buf in stream order (return 0) -- and
  *   the layer is normalised with the statistics of sync->global_rows rows (all ranks' R).  Backward:
  *   the two BatchNorm-backward sums travel the same way; parameter gradients stay local.
+ * Forward, need_wt0 bit 2 (value 4): wbuf already holds the operands of the CURRENT weights (prepared by
+ * pcb_prep_weights_table_* since the last update): the preparation launch is skipped, nothing else changes.
  * Forward, need_wt0 bit 1 (value 2): every layer is in eval mode and wbuf / stz still hold what an
  * earlier call with the same, unchanged parameters and running statistics left there -- operand
  * preparation and the per-layer BatchNorm finalize are skipped (inference with constant weights).

@@ -296,6 +296,37 @@ int prep_weights(int n, const long long *desc, float *zero, long zero_n, void *s
     return pcb_check_launch();
 }
 
+// The same for ANY number of layers, described by a table in device memory (8 int64 per layer as in `desc`:
+// w, wp, wt, C, k, kp, perm, 0): the operands of every stack of a network, prepared by one launch per optimiser
+// step (rowmlp.prepare_step) instead of one launch at the top of every stack's forward pass.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weights_table_kernel(const long long *__restrict__ table)
+{
+    const long long *d = table + 8L * blockIdx.y;
+    const float *const w = reinterpret_cast<const float *>(static_cast<uintptr_t>(d[0]));
+    T *const wp = reinterpret_cast<T *>(static_cast<uintptr_t>(d[1]));
+    T *const wt = reinterpret_cast<T *>(static_cast<uintptr_t>(d[2]));
+    const int C = (int)d[3], k = (int)d[4], kp = (int)d[5], perm = (int)d[6];
+    const int total = C * kp;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int c = e / kp, j = e - c * kp;
+        const int r = real_column(j, k, perm, RowVec<T>::E);
+        const T h = to_elem<T>(r >= 0 ? w[(long)c * k + r] : 0.0f);
+        wp[e] = h;
+        if (wt) wt[(long)j * C + c] = h;
+    }
+}
+
+template <typename T>
+int prep_weights_table(const long long *table, int n, long max_elems, void *stream)
+{
+    if (!table || n < 1 || n > 65535 || max_elems < 1) return PCB_ERR_INVALID_ARG;
+    long gx = (max_elems + 255) / 256;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(prep_weights_table_kernel<T>, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table);
+    return pcb_check_launch();
+}
+
 // Operands of a bias-only conv in one launch: w [n,k] fp32 -> wp [npad,kp] and wt [kp,npad] (zero
 // padded), bias [n] -> bp [npad] fp32.  gap = D > 0: the n outputs use the interpolate+concat
 // column layout (first D in place, the rest from column pad(D)), see real_column(.., -D).
@@ -490,6 +521,15 @@ int pcb_prep_weights_f32(int n, const long long *desc, void *stream)
 int pcb_prep_weights_zero_f32(int n, const long long *desc, float *zero, long zero_n, void *stream)
 {
     return prep_weights<float>(n, desc, zero, zero_n, stream);
+}
+
+int pcb_prep_weights_table_bf16(const long long *table, int n, long max_elems, void *stream)
+{
+    return prep_weights_table<pcb_bf16>(table, n, max_elems, stream);
+}
+int pcb_prep_weights_table_f32(const long long *table, int n, long max_elems, void *stream)
+{
+    return prep_weights_table<float>(table, n, max_elems, stream);
 }
 
 int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap, void *wp,

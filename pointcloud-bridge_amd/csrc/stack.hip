@@ -407,6 +407,9 @@ extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, co
     // need_wt0 bit 1: wbuf and stz still hold the operands and BatchNorm constants an earlier
     // eval-mode call prepared from the same, unchanged parameters -- no preparation, no finalize
     const bool ready = (need_wt0 & 2) != 0;
+    // bit 2: wbuf holds the operands of the current weights already (one table launch per optimiser step prepared
+    // every stack's): no preparation launch here
+    const bool wready = (need_wt0 & 4) != 0;
     need_wt0 &= 1;
     PCB_TRY(parse(L, desc, Kp, need_wt0, gathered, op.quantum, ly));
     if (!fdesc || (!x && !gathered) || (!wbuf && !(gathered && L == 1)) || !stz || !out || R <= 0 || pool < 0 ||
@@ -423,10 +426,13 @@ extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, co
 
     long stz_floats = 0;
     for (int l = 0; l < L; ++l) stz_floats += 10L * ly[l].C;
-    bool cleared = ready;  // stz is cleared by the first weight-preparation launch (or a memset if there is none)
+    // stz is cleared by the first weight-preparation launch (or a zero launch if there is none).  What needs clearing is
+    // the single accumulation slab of a backward reduction without slabs (rows 6, 7); with a slab buffer every row of
+    // stz is written before it is read, so a call with prepared weights and `parts` clears nothing.
+    bool cleared = ready || (wready && parts);
 
     // GEMM operands of all layers (chunks of 8 layers per launch)
-    for (int l0 = gathered ? 1 : 0; l0 < L && !ready; l0 += 8) {
+    for (int l0 = gathered ? 1 : 0; l0 < L && !ready && !wready; l0 += 8) {
         const int n = L - l0 < 8 ? L - l0 : 8;
         long long pd[8 * 8];
         for (int i = 0; i < n; ++i) {

@@ -179,12 +179,143 @@ _eval_operands = {}
 _generation = 0
 
 
-def note_parameter_update():
+def note_parameter_update(weights=True):
     """Invalidate the eval-mode operand cache: parameters or running statistics were updated by a path
     that does not bump tensor version counters (a flat-buffer optimizer step, a library-side
-    running-statistics update)."""
-    global _generation
+    running-statistics update).  weights=False: only running statistics changed (every training-mode
+    forward says so) -- the per-step operand table (prepare_step) stays valid."""
+    global _generation, _weights_generation
     _generation += 1
+    if weights:
+        _weights_generation += 1
+
+
+# ---------------------------------------------------------------------------------------------
+# Training: the GEMM operands of EVERY stack prepared by ONE launch per optimiser step.
+# A stack's forward pass used to open with its own small operand-preparation launch (~20 per PN2-MSG
+# step, each a dependent 5 us launch in front of the first GEMM).  The weights only change in the
+# optimiser step, so the trainer calls prepare_step() right after it: one kernel walks a table (in
+# device memory, rebuilt only when the set of stacks changes) of every registered stack's layers and
+# fills their persistent operand buffers; the forward passes that follow find their entry marked
+# prepared and tell the library to skip the launch (need_wt0 bit 2).  A stack registers itself the
+# first time it runs; an entry is valid for exactly the parameter tensors (storage addresses, version
+# counters, weight generation) it was prepared from -- anything else falls back to the per-stack launch.
+# ---------------------------------------------------------------------------------------------
+_weights_generation = 0
+_step_entries = {}
+_step_table = None        # (device int64 tensor, rows, max elements, mode code) per mode code, or None when stale
+_step_prepared = (-1, -1)  # (_step_serial, _weights_generation) of the last prepare_step
+_step_serial = 0
+_step_stats = [0, 0]   # stack calls that found their operands prepared / that prepared them themselves
+
+
+_step_enabled = True
+
+
+def set_step_operands(flag):
+    """False: every stack call prepares its own operands in a buffer of its own, as before prepare_step existed
+    (A/B runs, tests).  Returns the previous setting."""
+    global _step_enabled
+    old, _step_enabled = _step_enabled, bool(flag)
+    return old
+
+
+class _StepEntry:
+    __slots__ = ("refs", "ptrs", "rows", "wbuf", "serial", "versions", "code")
+
+    def alive(self):
+        return all(r() is not None for r in self.refs)
+
+
+def _step_rows(weights, Kp, perm, need_wt0, q):
+    """(C, k, kp, perm, wp offset, wt offset or -1) per layer with a weight -- the layout pcb_mlp_stack_* uses
+    inside wbuf (csrc/stack.hip: parse).  weights[0] is None for a gathered first layer (Kp = its width)."""
+    rows, off, kp = [], 0, Kp
+    for l, w in enumerate(weights):
+        if w is None:
+            continue
+        C = w.shape[0]
+        k = w.numel() // C
+        wp = off
+        off += C * kp
+        wt = -1
+        if l > 0 or need_wt0:
+            wt = off
+            off += C * kp
+        rows.append((l, C, k, kp, perm if l == 0 else 0, wp, wt))
+        kp = C
+    return rows, off
+
+
+def _step_operands(kind, weights, Kp, perm, need_wt0, m, nelem, dev):
+    """(wbuf, flag) for a training-mode stack call: the entry's persistent operand buffer and 4 if the last
+    prepare_step filled it from exactly these parameters, else 0 (the call prepares them itself)."""
+    global _step_table
+    if not _step_enabled:
+        return torch.empty(max(nelem, 1), dtype=m.dtype, device=dev), 0
+    first = next(w for w in weights if w is not None)
+    key = (kind, id(first), Kp, perm, len(weights), m.code, int(need_wt0))
+    ptrs = tuple(0 if w is None else w.data_ptr() for w in weights)
+    e = _step_entries.get(key)
+    if e is None or e.ptrs != ptrs or not e.alive() or e.wbuf.numel() != max(nelem, 1) or e.wbuf.device != dev:
+        e = _StepEntry()
+        e.refs = [weakref.ref(w) for w in weights if w is not None]
+        e.ptrs = ptrs
+        e.rows, _ = _step_rows(weights, Kp, perm, need_wt0, m.q)
+        e.wbuf = torch.empty(max(nelem, 1), dtype=m.dtype, device=dev)
+        e.serial = -1
+        e.versions = None
+        e.code = m.code
+        if len(_step_entries) > 4096:
+            _step_entries.clear()
+        _step_entries[key] = e
+        _step_table = None
+        return e.wbuf, 0
+    if (e.serial == _step_prepared[0] and _step_prepared[1] == _weights_generation
+            and e.versions == tuple(w._version for w in weights if w is not None)):
+        _step_stats[0] += 1
+        return e.wbuf, 4
+    _step_stats[1] += 1
+    return e.wbuf, 0
+
+
+def prepare_step():
+    """Call after every optimiser step (the trainer and bench.py do): prepares the operands of all registered
+    stacks from the current weights with one launch per row type.  Purely an optimisation: stacks whose entry is
+    not (or no longer) valid prepare their own operands as before.  An entry is trusted until a version counter
+    of its weights moves or note_parameter_update() is called: code that edits weights through `.data` between
+    this call and the forward pass must call one of the two (parallel.FlatAdam does)."""
+    global _step_table, _step_prepared, _step_serial
+    dead = [k for k, e in _step_entries.items() if not e.alive()]
+    for k in dead:
+        del _step_entries[k]
+        _step_table = None
+    if not _step_entries:
+        return
+    if _step_table is None:
+        tables = {}
+        for e in _step_entries.values():
+            live = [r() for r in e.refs]
+            base, es = e.wbuf.data_ptr(), e.wbuf.element_size()
+            it = iter(live)
+            vals, most = tables.setdefault(e.code, ([], [0]))
+            for (l, C, k, kp, perm, wp, wt) in e.rows:
+                w = next(it)
+                vals += [w.data_ptr(), base + es * wp, 0 if wt < 0 else base + es * wt, C, k, kp, perm, 0]
+                most[0] = max(most[0], C * kp)
+        dev = next(iter(_step_entries.values())).wbuf.device
+        _step_table = {code: (torch.tensor(vals, dtype=torch.int64, device=dev), len(vals) // 8, most[0])
+                       for code, (vals, most) in tables.items()}
+    _step_serial += 1
+    dev = next(iter(_step_entries.values())).wbuf.device
+    with on_device(dev):
+        for code, (table, n, most) in _step_table.items():
+            sfx = "bf16" if code == _MODES["bf16"].code else "f32"
+            _launch("pcb_prep_weights_table_" + sfx, n, table.data_ptr(), n, most)
+    for e in _step_entries.values():
+        e.serial = _step_serial
+        e.versions = tuple(r()._version for r in e.refs)
+    _step_prepared = (_step_serial, _weights_generation)
 
 
 def _eval_lookup(layers, first, extra):
@@ -307,9 +438,14 @@ class _FusedStack(torch.autograd.Function):
                 wbuf, stz = hit
                 ready = 2
         if training:
-            note_parameter_update()  # running statistics change under the eval cache's feet
+            note_parameter_update(weights=False)  # running statistics change under the eval cache's feet
         if not ready:
-            wbuf = torch.empty(lib.pcb_mlp_stack_wbuf_elems(L, desc, Kp, int(need_dx)), dtype=m.dtype, device=dev)
+            nw = lib.pcb_mlp_stack_wbuf_elems(L, desc, Kp, int(need_dx))
+            if cache_key is None:
+                # the stack's persistent operand buffer; flag 4: already prepared from these weights (prepare_step)
+                wbuf, ready = _step_operands("stack", [t[0] for t in layers], Kp, perm, need_dx, m, nw, dev)
+            else:
+                wbuf = torch.empty(nw, dtype=m.dtype, device=dev)
         fdesc = (ctypes.c_double * (2 * L))(*[float(v) for t in layers for v in (t[7], t[8])])
         C = widths[-1]
         if pool:
@@ -492,10 +628,13 @@ class _GatheredStack(torch.autograd.Function):
                 wbuf, stz = hit
                 ready = 2
         if training:
-            note_parameter_update()
+            note_parameter_update(weights=False)
         if not ready:
             nw = lib.pcb_mlp_stack_wbuf_elems(L, desc, 0, 0)
-            wbuf = torch.empty(max(nw, 1), dtype=torch.bfloat16, device=dev)
+            if L > 1 and cache_key is None:
+                wbuf, ready = _step_operands("gathered", [None] + [t[0] for t in layers[1:]], widths[0], 0, False, m, nw, dev)
+            else:
+                wbuf = torch.empty(max(nw, 1), dtype=torch.bfloat16, device=dev)
         fdesc = (ctypes.c_double * (2 * L))(*[float(x) for t in layers for x in (t[7], t[8])])
         gather = (ctypes.c_longlong * 12)(
             u.data_ptr(), 0 if v is None else v.data_ptr(), idx.data_ptr(), B, N, S, ns,

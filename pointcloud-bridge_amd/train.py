@@ -16,7 +16,7 @@ the parts of their loops that touch the hot path, with the same hyper-parameters
 """
 import torch
 
-from . import losses, parallel
+from . import losses, parallel, rowmlp
 
 
 def synthetic_scenes(num_scenes, num_points, num_classes=5, seed=0, device="cpu"):
@@ -106,6 +106,7 @@ class Trainer:
         if self.bucket is not None:
             self.bucket.reduce()
         self.opt.step()
+        rowmlp.prepare_step()   # GEMM operands of every stack from the updated weights, one launch
         return loss.detach()
 
     @torch.no_grad()

@@ -156,3 +156,87 @@ def test_bench_on_a_one_rank_rccl_group(tmp_path, mode):
         assert abs(da["losses"][0] - db["losses"][0]) <= 1e-6 * abs(da["losses"][0])  # the first forward pass: no update yet
         ga, gb = da["first_grad"], db["first_grad"]
         assert float((ga - gb).norm() / ga.norm()) < 1e-4  # the all-reduced gradient IS the local one
+
+
+def _msg_pair():
+    from pointcloud_bridge_amd.models.containers import PointNet2MSG
+    torch.manual_seed(42)
+    a = PointNet2MSG(5).cuda().train()
+    torch.manual_seed(42)
+    b = PointNet2MSG(5).cuda().train()
+    for m in list(a.modules()) + list(b.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return a, b
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_prepare_step_changes_nothing_but_the_launch_count(precision):
+    """rowmlp.prepare_step(): the operands of every stack from ONE launch after the optimiser step.  Two identical
+    networks train three Adam steps on the same batches, one with prepare_step() after every update, one without;
+    their eval logits then agree (fp32 rows: to rounding of the scatter-add order; bf16: to the run-to-run noise of
+    that mode), the stacks of the first really skipped their own preparation, and an in-place edit of a weight
+    after prepare_step() (version counter moves) is honoured by the next forward pass."""
+    from pointcloud_bridge_amd import rowmlp
+    a, b = _msg_pair()
+    rowmlp.set_precision(precision)
+    try:
+        oa, ob = torch.optim.Adam(a.parameters(), lr=1e-3), torch.optim.Adam(b.parameters(), lr=1e-3)
+        g = torch.Generator().manual_seed(1)
+        B, N = 2, 2048
+        for step in range(3):
+            v = torch.randn(B, N, 3, generator=g)
+            xyz = (v / v.norm(dim=-1, keepdim=True) * torch.rand(B, N, 1, generator=g) ** (1 / 3)).cuda()
+            col = torch.rand(B, N, 3, generator=g).cuda()
+            lab = torch.randint(0, 5, (B, N), generator=g).cuda()
+            hits0 = rowmlp._step_stats[0]
+            for net, opt, prep in ((a, oa, True), (b, ob, False)):
+                rowmlp.set_step_operands(prep)  # network b: every stack prepares its own operands, as before
+                torch.manual_seed(100 + step)   # FPS start indices: the same CPU-generator draw for both
+                opt.zero_grad(set_to_none=True)
+                F.cross_entropy(net(xyz, col), lab).backward()
+                opt.step()
+                if prep:
+                    rowmlp.prepare_step()
+            if step == 0:
+                assert rowmlp._step_stats[0] == hits0  # first step: the stacks only registered
+            else:
+                assert rowmlp._step_stats[0] - hits0 >= 15, rowmlp._step_stats  # later steps: found prepared
+        rowmlp.set_step_operands(True)
+        # the two trajectories stay together as far as Adam lets two runs of one command (scatter-adds by atomics,
+        # sign-like first updates: see test_bench_two_ranks_strong_scaling_equal_the_one_rank_run)
+        a.eval(), b.eval()
+        with torch.no_grad():
+            torch.manual_seed(9)
+            la = a(xyz, col)
+            torch.manual_seed(9)
+            lb = b(xyz, col)
+        assert float((la - lb).abs().max() / lb.abs().max()) < (3e-2 if precision == "fp32" else 1e-1)
+        # same weights in both: a forward pass on prepared operands IS the forward pass on self-prepared ones
+        b.load_state_dict(a.state_dict())
+        a.train(), b.train()
+        rowmlp.prepare_step()
+        hits = rowmlp._step_stats[0]
+        torch.manual_seed(10)
+        ya = a(xyz, col)
+        assert rowmlp._step_stats[0] - hits >= 15
+        rowmlp.set_step_operands(False)
+        torch.manual_seed(10)
+        yb = b(xyz, col)
+        assert torch.equal(ya, yb)
+        # a weight edited after prepare_step(): the stale operands must not be used
+        rowmlp.set_step_operands(True)
+        b.load_state_dict(a.state_dict())   # (running statistics moved in the forward passes above)
+        rowmlp.prepare_step()
+        with torch.no_grad():
+            for net in (a, b):
+                net.sa1.conv_blocks[0][0].weight.mul_(1.5)
+        torch.manual_seed(11)
+        ya = a(xyz, col)
+        rowmlp.set_step_operands(False)
+        torch.manual_seed(11)
+        yb = b(xyz, col)
+        assert torch.equal(ya, yb)
+    finally:
+        rowmlp.set_step_operands(True)
+        rowmlp.set_precision("fp32")
