@@ -473,10 +473,11 @@ int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *
  * -D < 0 = interpolate+concat rows (first D columns in place, the rest from column pad(D)). */
 int pcb_prep_weights_bf16(int n, const long long *desc, void *stream);
 int pcb_prep_weights_f32(int n, const long long *desc, void *stream);
-/* The same for any number of layers from a table in DEVICE memory (n rows of 8 int64 as above; max_elems = the
- * largest C*kp among them): the operands of every stack of a network in one launch per optimiser step. */
-int pcb_prep_weights_table_bf16(const long long *table, int n, long max_elems, void *stream);
-int pcb_prep_weights_table_f32(const long long *table, int n, long max_elems, void *stream);
+/* The same for any number of layers from a table in DEVICE memory: n rows of 8 int64 as above whose last slot
+ * holds the row's first workgroup -- a layer takes ceil(C*kp / 1024) workgroups, rows in ascending order, `blocks` =
+ * their total: the operands of every stack of a network in one launch per optimiser step. */
+int pcb_prep_weights_table_bf16(const long long *table, int n, long blocks, void *stream);
+int pcb_prep_weights_table_f32(const long long *table, int n, long blocks, void *stream);
 /* The same, and `zero` [zero_n] fp32 is cleared by the same launch (a stack's constants buffer). */
 int pcb_prep_weights_zero_bf16(int n, const long long *desc, float *zero, long zero_n, void *stream);
 int pcb_prep_weights_zero_f32(int n, const long long *desc, float *zero, long zero_n, void *stream);

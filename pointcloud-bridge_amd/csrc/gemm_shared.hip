@@ -300,15 +300,27 @@ int prep_weights(int n, const long long *desc, float *zero, long zero_n, void *s
 // w, wp, wt, C, k, kp, perm, 0): the operands of every stack of a network, prepared by one launch per optimiser
 // step (rowmlp.prepare_step) instead of one launch at the top of every stack's forward pass.
 template <typename T>
-__global__ __launch_bounds__(256) void prep_weights_table_kernel(const long long *__restrict__ table)
+__global__ __launch_bounds__(256) void prep_weights_table_kernel(const long long *__restrict__ table, int n)
 {
-    const long long *d = table + 8L * blockIdx.y;
+    // slot [7] of a row = the first workgroup of its layer (1024 elements per workgroup, rows in ascending
+    // order): every workgroup finds its layer by bisection, so the grid holds no idle workgroups however
+    // unequal the layers are (a 2-D grid sized for the largest layer spent 20 us dispatching empty ones)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[8L * mid + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long *d = table + 8L * lo;
     const float *const w = reinterpret_cast<const float *>(static_cast<uintptr_t>(d[0]));
     T *const wp = reinterpret_cast<T *>(static_cast<uintptr_t>(d[1]));
     T *const wt = reinterpret_cast<T *>(static_cast<uintptr_t>(d[2]));
     const int C = (int)d[3], k = (int)d[4], kp = (int)d[5], perm = (int)d[6];
     const int total = C * kp;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int base = ((int)blockIdx.x - (int)d[7]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = base + u * 256 + threadIdx.x;
+        if (e >= total) break;
         const int c = e / kp, j = e - c * kp;
         const int r = real_column(j, k, perm, RowVec<T>::E);
         const T h = to_elem<T>(r >= 0 ? w[(long)c * k + r] : 0.0f);
@@ -318,12 +330,10 @@ __global__ __launch_bounds__(256) void prep_weights_table_kernel(const long long
 }
 
 template <typename T>
-int prep_weights_table(const long long *table, int n, long max_elems, void *stream)
+int prep_weights_table(const long long *table, int n, long blocks, void *stream)
 {
-    if (!table || n < 1 || n > 65535 || max_elems < 1) return PCB_ERR_INVALID_ARG;
-    long gx = (max_elems + 255) / 256;
-    if (gx > 512) gx = 512;
-    hipLaunchKernelGGL(prep_weights_table_kernel<T>, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table);
+    if (!table || n < 1 || blocks < 1 || blocks > 0x7fffffffL) return PCB_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(prep_weights_table_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, n);
     return pcb_check_launch();
 }
 
@@ -523,13 +533,13 @@ int pcb_prep_weights_zero_f32(int n, const long long *desc, float *zero, long ze
     return prep_weights<float>(n, desc, zero, zero_n, stream);
 }
 
-int pcb_prep_weights_table_bf16(const long long *table, int n, long max_elems, void *stream)
+int pcb_prep_weights_table_bf16(const long long *table, int n, long blocks, void *stream)
 {
-    return prep_weights_table<pcb_bf16>(table, n, max_elems, stream);
+    return prep_weights_table<pcb_bf16>(table, n, blocks, stream);
 }
-int pcb_prep_weights_table_f32(const long long *table, int n, long max_elems, void *stream)
+int pcb_prep_weights_table_f32(const long long *table, int n, long blocks, void *stream)
 {
-    return prep_weights_table<float>(table, n, max_elems, stream);
+    return prep_weights_table<float>(table, n, blocks, stream);
 }
 
 int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap, void *wp,
