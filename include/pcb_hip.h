@@ -474,7 +474,7 @@ int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *
 int pcb_prep_weights_bf16(int n, const long long *desc, void *stream);
 int pcb_prep_weights_f32(int n, const long long *desc, void *stream);
 /* The same for any number of layers from a table in DEVICE memory: n rows of 8 int64 as above whose last slot
- * holds the row's first workgroup -- a layer takes ceil(C*kp / 1024) workgroups, rows in ascending order, `blocks` =
+ * holds the row's first workgroup -- a layer takes ceil(C/32)*ceil(kp/32) workgroups, rows in ascending order, `blocks` =
  * their total: the operands of every stack of a network in one launch per optimiser step. */
 int pcb_prep_weights_table_bf16(const long long *table, int n, long blocks, void *stream);
 int pcb_prep_weights_table_f32(const long long *table, int n, long blocks, void *stream);

@@ -302,7 +302,7 @@ int prep_weights(int n, const long long *desc, float *zero, long zero_n, void *s
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weights_table_kernel(const long long *__restrict__ table, int n)
 {
-    // slot [7] of a row = the first workgroup of its layer (1024 elements per workgroup, rows in ascending
+    // slot [7] of a row = the first workgroup of its layer (one 32 x 32 tile per workgroup, rows in ascending
     // order): every workgroup finds its layer by bisection, so the grid holds no idle workgroups however
     // unequal the layers are (a 2-D grid sized for the largest layer spent 20 us dispatching empty ones)
     int lo = 0, hi = n - 1;
@@ -315,17 +315,31 @@ __global__ __launch_bounds__(256) void prep_weights_table_kernel(const long long
     T *const wp = reinterpret_cast<T *>(static_cast<uintptr_t>(d[1]));
     T *const wt = reinterpret_cast<T *>(static_cast<uintptr_t>(d[2]));
     const int C = (int)d[3], k = (int)d[4], kp = (int)d[5], perm = (int)d[6];
-    const int total = C * kp;
-    const int base = ((int)blockIdx.x - (int)d[7]) * 1024;
+    // a workgroup = one 32 x 32 tile (rows c, columns j) of the layer: W is read and wp written along j, the
+    // transpose goes through LDS so that wt is written along c as well (2-byte stores a row of C apart were
+    // the whole cost of this kernel)
+    __shared__ T tile[32][33];
+    const int tiles_j = (kp + 31) / 32;
+    const int tid = (int)blockIdx.x - (int)d[7];
+    const int c0 = (tid / tiles_j) * 32, j0 = (tid % tiles_j) * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int e = base + u * 256 + threadIdx.x;
-        if (e >= total) break;
-        const int c = e / kp, j = e - c * kp;
-        const int r = real_column(j, k, perm, RowVec<T>::E);
-        const T h = to_elem<T>(r >= 0 ? w[(long)c * k + r] : 0.0f);
-        wp[e] = h;
-        if (wt) wt[(long)j * C + c] = h;
+        const int c = c0 + ly + 8 * u, j = j0 + lx;
+        T h = to_elem<T>(0.0f);
+        if (c < C && j < kp) {
+            const int r = real_column(j, k, perm, RowVec<T>::E);
+            h = to_elem<T>(r >= 0 ? w[(long)c * k + r] : 0.0f);
+            wp[(long)c * kp + j] = h;
+        }
+        tile[ly + 8 * u][lx] = h;
+    }
+    if (!wt) return;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = j0 + ly + 8 * u, c = c0 + lx;
+        if (c < C && j < kp) wt[(long)j * C + c] = tile[lx][ly + 8 * u];
     }
 }
 

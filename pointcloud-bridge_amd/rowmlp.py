@@ -298,11 +298,11 @@ def prepare_step():
             live = [r() for r in e.refs]
             base, es = e.wbuf.data_ptr(), e.wbuf.element_size()
             it = iter(live)
-            vals, most = tables.setdefault(e.code, ([], [0]))   # most[0]: workgroups so far (1024 elements each)
+            vals, most = tables.setdefault(e.code, ([], [0]))   # most[0]: workgroups so far (one 32 x 32 tile each)
             for (l, C, k, kp, perm, wp, wt) in e.rows:
                 w = next(it)
                 vals += [w.data_ptr(), base + es * wp, 0 if wt < 0 else base + es * wt, C, k, kp, perm, most[0]]
-                most[0] += (C * kp + 1023) // 1024
+                most[0] += ((C + 31) // 32) * ((kp + 31) // 32)
         dev = next(iter(_step_entries.values())).wbuf.device
         _step_table = {code: (torch.tensor(vals, dtype=torch.int64, device=dev), len(vals) // 8, most[0])
                        for code, (vals, most) in tables.items()}
