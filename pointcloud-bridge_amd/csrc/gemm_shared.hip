@@ -53,7 +53,6 @@ struct ReduceBatch {
 };
 __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch batch)
 {
-    __shared__ float red[16][64];
     const PendingReduce r = batch.e[blockIdx.y];
     const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
     const long total = r.elems + (r.vec ? r.vlen : 0);
@@ -80,38 +79,71 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceBatch ba
         }
         return;
     }
-    // many slabs: at most 1024 workgroups walk the 64-element chunks (more, shorter-lived ones measured slower)
+    // many slabs: 256 elements x 16 split-lanes per workgroup and step -- a lane adds four consecutive elements
+    // (one 16-byte load per slab; element counts and slab strides are multiples of 4), eight slabs' loads in
+    // flight, adds in split order; at most 1024 workgroups (more, shorter-lived ones measured slower)
+    __shared__ float4 red4[16][64];
     const long nblk = gridDim.x < 1024 ? gridDim.x : 1024;
     if (blockIdx.x >= nblk) return;
-    for (long e0 = (long)blockIdx.x * 64; e0 < total; e0 += nblk * 64) {
-        const long e = e0 + ex;
-        float a = 0.0f;
-        if (e < total) {
-            // eight splits' loads in flight per step, adds in split order
-            for (int s0 = sy; s0 < r.splits; s0 += 16 * 8) {
-                float v[8];
+    // (small matrices keep the 64-element chunks: their few chunks should spread over as many workgroups as possible)
+    const bool vec_ok = total >= 32768 && ((r.stride | total) & 3) == 0 && (reinterpret_cast<uintptr_t>(r.part) & 15) == 0;
+    const long per_iter = vec_ok ? 256 : 64;
+    for (long e0 = (long)blockIdx.x * per_iter; e0 < total; e0 += nblk * per_iter) {
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (vec_ok) {
+            const long e = e0 + 4L * ex;
+            if (e < total) {
+                for (int s0 = sy; s0 < r.splits; s0 += 16 * 8) {
+                    float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int sp = s0 + 16 * u;
-                    const float x = r.part[(long)(sp < r.splits ? sp : r.splits - 1) * r.stride + e];
-                    v[u] = sp < r.splits ? x : 0.0f;
+                    for (int u = 0; u < 8; ++u) {
+                        const int sp = s0 + 16 * u;
+                        v[u] = *reinterpret_cast<const float4 *>(r.part + (long)(sp < r.splits ? sp : r.splits - 1) * r.stride + e);
+                        if (sp >= r.splits) v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+                    }
                 }
+            }
+        } else {
+            const long e = e0 + ex;
+            if (e < total) {
+                for (int s0 = sy; s0 < r.splits; s0 += 16 * 8) {
+                    float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a += v[u];
+                    for (int u = 0; u < 8; ++u) {
+                        const int sp = s0 + 16 * u;
+                        const float x = r.part[(long)(sp < r.splits ? sp : r.splits - 1) * r.stride + e];
+                        v[u] = sp < r.splits ? x : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a.x += v[u];
+                }
             }
         }
-        red[sy][ex] = a;
+        red4[sy][ex] = a;
         __syncthreads();
-        if (sy == 0 && e < total) {
-            float t = 0.0f;
+        if (sy == 0) {
+            float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) t += red[i][ex];
-            if (e >= r.elems) {
-                r.vec[e - r.elems] = t;
-            } else {
-                const long m = e / r.N;
-                const int c = real_column((int)(e - m * r.N), r.k, r.perm, r.quantum);
-                if (c >= 0) r.dW[m * r.k + c] = t;
+            for (int i = 0; i < 16; ++i) {
+                const float4 q = red4[i][ex];
+                t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+            }
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+            const int cnt = vec_ok ? 4 : 1;
+            for (int i = 0; i < cnt; ++i) {
+                const long e = vec_ok ? e0 + 4L * ex + i : e0 + ex;
+                if (e >= total) break;
+                if (e >= r.elems) {
+                    r.vec[e - r.elems] = tv[i];
+                } else {
+                    const long m = e / r.N;
+                    const int c = real_column((int)(e - m * r.N), r.k, r.perm, r.quantum);
+                    if (c >= 0) r.dW[m * r.k + c] = tv[i];
+                }
             }
         }
         __syncthreads();
@@ -123,12 +155,12 @@ thread_local int g_npending = -1;  // < 0: every reduction runs right behind its
 int launch_reduce_batch(const ReduceBatch &batch, int n, hipStream_t st)
 {
     // workgroups an entry can use: few slabs -> 1024 elements per workgroup and step (at most 2048 of them),
-    // many slabs -> 64-element chunks walked by at most 1024 workgroups; the grid serves the neediest entry,
+    // many slabs -> 256-element chunks walked by at most 1024 workgroups; the grid serves the neediest entry,
     // the others' surplus workgroups leave at once
     long blocks = 1;
     for (int i = 0; i < n; ++i) {
         const long total = batch.e[i].elems + batch.e[i].vlen;
-        long b = batch.e[i].splits <= 16 ? (total + 1023) / 1024 : (total + 63) / 64;
+        long b = batch.e[i].splits <= 16 ? (total + 1023) / 1024 : (total >= 32768 ? (total + 255) / 256 : (total + 63) / 64);
         const long cap = batch.e[i].splits <= 16 ? 2048 : 1024;
         b = b > cap ? cap : b;
         blocks = b > blocks ? b : blocks;
