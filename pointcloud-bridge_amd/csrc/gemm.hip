@@ -36,6 +36,8 @@ typedef unsigned short u16;
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
@@ -59,7 +61,6 @@ __device__ __forceinline__ uint4 pack8(const float *f)
 // Activations as one select on a per-launch slope (0 ReLU, 0.2 LeakyReLU, 1 none): testing the
 // activation code per element would put scalar branches into the innermost prologue loops.
 __device__ __forceinline__ float act_slope(int act) { return act == 1 ? 0.0f : (act == 2 ? 0.2f : 1.0f); }
-__device__ __forceinline__ float act_fwd(float u, float slope) { return u > 0.0f ? u : fmaf(slope, u, 0.0f); }
 __device__ __forceinline__ float act_grad(float u, float slope) { return u > 0.0f ? 1.0f : slope; }
 
 // ---- operand prologues ------------------------------------------------------------------------
@@ -148,11 +149,40 @@ struct Raw {
         if (PRO == PRO_PLAIN) return make_uint4(v0.x & keep, v0.y & keep, v0.z & keep, v0.w & keep);
         float f[8];
         if (PRO == PRO_BNACT) {
-            unpack8(v0, f);
+            // (packed pairs per dword, see PRO_DY below)
+            const uint32_t xw[4] = {v0.x, v0.y, v0.z, v0.w};
+            uint32_t o[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] = act_fwd(fmaf(f[i], k.scale[i], k.shift[i]), slope);
-            const uint4 r = pack8(f);
-            return make_uint4(r.x & keep, r.y & keep, r.z & keep, r.w & keep);
+            for (int d = 0; d < 4; ++d) {
+                const f32x2 xv = {__uint_as_float(xw[d] << 16), __uint_as_float(xw[d] & 0xffff0000u)};
+                const f32x2 sc = {k.scale[2 * d], k.scale[2 * d + 1]}, sh = {k.shift[2 * d], k.shift[2 * d + 1]};
+                const f32x2 u = __builtin_elementwise_fma(xv, sc, sh);
+                const f32x2 zero = {0.0f, 0.0f}, sl = {slope, slope};
+                const f32x2 neg = __builtin_elementwise_fma(sl, u, zero);   // act_fwd: fmaf(slope, u, 0)
+                const f32x2 r = {u.x > 0.0f ? u.x : neg.x, u.y > 0.0f ? u.y : neg.y};
+                o[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t)) & keep;
+            }
+            return make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (PRO == PRO_DY) {
+            // the two values of one dword stay one packed-fp32 pair from unpack to pack: v_pk_fma / v_pk_mul on the
+            // pair, one v_cvt_pk_bf16_f32 back into the dword (left to itself the vectoriser paired the low halves
+            // of two dwords and re-shuffled the results: four more vector instructions per dword pair)
+            const uint32_t zw[4] = {v0.x, v0.y, v0.z, v0.w}, yw[4] = {v1.x, v1.y, v1.z, v1.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const f32x2 yv = {__uint_as_float(yw[d] << 16), __uint_as_float(yw[d] & 0xffff0000u)};
+                const f32x2 zv = {__uint_as_float(zw[d] << 16), __uint_as_float(zw[d] & 0xffff0000u)};
+                const f32x2 sc = {k.scale[2 * d], k.scale[2 * d + 1]}, sh = {k.shift[2 * d], k.shift[2 * d + 1]};
+                const f32x2 pp = {k.p[2 * d], k.p[2 * d + 1]}, qq = {k.q[2 * d], k.q[2 * d + 1]};
+                const f32x2 u = __builtin_elementwise_fma(yv, sc, sh);
+                const f32x2 g = {u.x > 0.0f ? 1.0f : slope, u.y > 0.0f ? 1.0f : slope};
+                const f32x2 du = zv * g;
+                const f32x2 r = __builtin_elementwise_fma(sc, du, __builtin_elementwise_fma(pp, yv, qq));
+                o[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t)) & keep;  // one v_cvt_pk_bf16_f32
+            }
+            return make_uint4(o[0], o[1], o[2], o[3]);
         }
         float y[8];
         unpack8(v1, y);
@@ -900,8 +930,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     const Operand A = local_copy(A_arg);
     const Operand B = local_copy(B_arg);
     const float a_slope = act_slope(A.act), b_slope = act_slope(B.act);
-    __shared__ __attribute__((aligned(16))) u16 As[TN_RS * TN_LD];
-    __shared__ __attribute__((aligned(16))) u16 Bs[TN_RS * TN_LD];
+    __shared__ __attribute__((aligned(16))) u16 As[2 * TN_RS * TN_LD];   // two stage buffers each
+    __shared__ __attribute__((aligned(16))) u16 Bs[2 * TN_RS * TN_LD];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -950,14 +980,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     const int tr_row = 8 * (grp >> 1) + (gi >> 2);
     const int tr_col = 16 * (grp & 1) + 4 * (gi & 3);
 
-    if (r_begin < r_end) fetch(r_begin);
+    // Two LDS stage buffers, ONE barrier per stage: while the waves multiply stage s out of buffer s & 1, the
+    // registers hold stage s+1 (its loads were issued before the previous barrier); it is transformed and parked in
+    // the other buffer behind the MFMAs, the loads of stage s+2 go out, and the barrier at the end of the step both
+    // publishes buffer (s+1) & 1 and retires the reads of buffer s & 1.
     float asum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (long r0 = r_begin; r0 < r_end; r0 += TN_RS) {
+    auto park = [&](int buf) {
+        u16 *const Ab = As + buf * (TN_RS * TN_LD);
+        u16 *const Bb = Bs + buf * (TN_RS * TN_LD);
 #pragma unroll
         for (int i = 0; i < TN_NCH; ++i) {
             const uint4 av = ra[i].finish(ka, a_slope);
-            *reinterpret_cast<uint4 *>(&As[(rrow + 16 * i) * TN_LD + chunk * 8]) = av;
-            *reinterpret_cast<uint4 *>(&Bs[(rrow + 16 * i) * TN_LD + chunk * 8]) = rb[i].finish(kb, b_slope);
+            *reinterpret_cast<uint4 *>(&Ab[(rrow + 16 * i) * TN_LD + chunk * 8]) = av;
+            *reinterpret_cast<uint4 *>(&Bb[(rrow + 16 * i) * TN_LD + chunk * 8]) = rb[i].finish(kb, b_slope);
             if (ASUM) {
                 float f[8];
                 unpack8(av, f);  // rows outside the split are zero already
@@ -965,15 +1000,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
                 for (int e = 0; e < 8; ++e) asum[e] += f[e];
             }
         }
-        __syncthreads();
-        if (r0 + TN_RS < r_end) fetch(r0 + TN_RS);
+    };
+    if (r_begin < r_end) {
+        fetch(r_begin);
+        park(0);
+        if (r_begin + TN_RS < r_end) fetch(r_begin + TN_RS);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (long r0 = r_begin; r0 < r_end; r0 += TN_RS, cur ^= 1) {
+        const u16 *const Ab = As + cur * (TN_RS * TN_LD);
+        const u16 *const Bb = Bs + cur * (TN_RS * TN_LD);
 #pragma unroll
         for (int ks = 0; ks < TN_RS / 16; ++ks) {
             bf16x8 af[2], bf[2];
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                const u16 *pa = &As[(ks * 16 + tr_row) * TN_LD + wm * 64 + x * 32 + tr_col];
-                const u16 *pb = &Bs[(ks * 16 + tr_row) * TN_LD + wn * 64 + x * 32 + tr_col];
+                const u16 *pa = &Ab[(ks * 16 + tr_row) * TN_LD + wm * 64 + x * 32 + tr_col];
+                const u16 *pb = &Bb[(ks * 16 + tr_row) * TN_LD + wn * 64 + x * 32 + tr_col];
                 typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
                 const s16x4 a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pa);
                 const s16x4 a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pa + 4 * TN_LD));
@@ -987,6 +1031,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (r0 + TN_RS < r_end) {
+            park(cur ^ 1);
+            if (r0 + 2 * TN_RS < r_end) fetch(r0 + 2 * TN_RS);
         }
         __syncthreads();
     }
