@@ -239,6 +239,7 @@ class Run:
         ONE hipGraph.  The CPU-generator draws for FPS stay on the host (StaticSampling.draw), the
         gradient all-reduce and the fused Adam step stay outside the graph.  One resident batch (the
         graph's tensors are fixed)."""
+        from pointcloud_bridge_amd import ops
         from pointcloud_bridge_amd.models import pointnet2_utils as pu
         model, bucket, opt = self.model, self.bucket, self.opt
         # the graph's tensors are fixed: the step's batch is copied into them before every replay, and the NEXT
@@ -264,6 +265,8 @@ class Run:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     static.compute(xyz_next)     # pyramid of the next step's batch, beside the backward pass
+                # the persistent backward GEMMs of the first stacks leave the pyramid's CUs alone (ops.apply_concurrency_hint)
+                ops.set_background_work(torch.cuda.Event(), 2 * xyz.shape[0])
             loss.backward()
             if static is not None:
                 torch.cuda.current_stream().wait_stream(side)

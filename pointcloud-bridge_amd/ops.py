@@ -81,11 +81,14 @@ def kernel_timer_read(category):
 # is pending the library is told to size those grids for the rest of the chip.
 _background = None  # (event, busy_cus)
 _hint_now = 0
+_capture_calls = 0
+_GRAPH_HINT_CALLS = int(os.environ.get("PCB_GRAPH_HINT_CALLS", "8"))
 
 
 def set_background_work(event, busy_cus):
-    global _background
+    global _background, _capture_calls
     _background = (event, int(busy_cus))
+    _capture_calls = 0
 
 
 def apply_concurrency_hint():
@@ -94,10 +97,14 @@ def apply_concurrency_hint():
     want = 0
     if _background is not None:
         if torch.cuda.is_current_stream_capturing():
-            # a captured step runs beside its own FPS pyramid but cannot ask whether that is over;
-            # the pyramid lasts ~1.2 ms of a 5 ms backward pass, so the grids stay full (measured:
-            # 10.6 ms/step against 12.4 with the hint held for the whole step; PCB_GRAPH_HINT=1 for A/B)
-            want = _background[1] if os.environ.get("PCB_GRAPH_HINT", "0") == "1" else 0
+            # a captured step runs beside its own FPS pyramid but cannot ask whether that is over: the pyramid
+            # lasts ~1.5 ms of a 5 ms backward pass.  Holding the hint for the whole step costs more than it
+            # saves (measured: 12.4 against 10.6 ms/step, round 1); holding it for the first n stack calls after
+            # the fork -- the backward passes that do run beside the pyramid -- pays: PN2-MSG, one box,
+            # n = 0 / 4 / 8 / 12 / 20: 7.63 / 7.59 / 7.46 / 7.47 / 7.57 ms per step (PCB_GRAPH_HINT_CALLS, default 8).
+            global _capture_calls
+            _capture_calls += 1
+            want = _background[1] if _capture_calls <= _GRAPH_HINT_CALLS else 0
         elif _background[0].query():
             _background = None          # finished: the GPU is ours again
         else:
