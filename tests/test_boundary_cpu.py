@@ -53,6 +53,75 @@ def test_argument_validation_without_gpu(lib):
         lib.check(-2, "x")
 
 
+def _desc(widths, Kp, gathered=False):
+    """Host descriptor of pcb_mlp_stack_* (16 int64 per layer) with dummy non-null pointers."""
+    vals, kp = [], Kp
+    for l, C in enumerate(widths):
+        w = 0 if (gathered and l == 0) else 64
+        vals += [w, 0, 0, 0, 0, 0, C, 0 if w == 0 else kp, 1, 64, 0, 0, 0, 0, 0, 0]
+        kp = C
+    return (ctypes.c_longlong * len(vals))(*vals)
+
+
+def test_operand_table_layout_mirrors_the_stack_runtime(lib):
+    """rowmlp.prepare_step fills every stack's operand buffer from a table built on the host: the offsets it
+    computes (rowmlp._step_rows) must be the layout csrc/stack.hip's parse() uses inside wbuf -- checked through the
+    one number the library exposes, pcb_mlp_stack_wbuf_elems, and the no-overlap / in-order structure of the rows."""
+    import torch.nn as nn
+    from pointcloud_bridge_amd import rowmlp
+    L = lib.load()
+    for widths, Kp, need in (([64, 64, 128], 8, 0), ([64, 64, 128], 8, 1), ([1024, 256], 1536, 1), ([384], 264, 0), ([16], 8, 1)):
+        ws, kin = [], Kp
+        for C in widths:
+            ws.append(nn.Parameter(torch.zeros(C, kin if ws else max(Kp - 2, 1))))   # layer 0: real k < padded Kp
+            kin = C
+        rows, total = rowmlp._step_rows(ws, Kp, 0, need, 8)
+        assert total == L.pcb_mlp_stack_wbuf_elems(len(widths), _desc(widths, Kp), Kp, need)
+        end = 0
+        for (l, C, k, kp, perm, wp, wt) in rows:
+            assert wp == end and kp == (Kp if l == 0 else widths[l - 1]) and k == ws[l].shape[1]
+            end = wp + C * kp
+            if l > 0 or need:
+                assert wt == end
+                end += C * kp
+            else:
+                assert wt == -1
+        assert end == total
+    # gathered first layer: no weights of its own, the following layers read rows of its width
+    ws = [None, nn.Parameter(torch.zeros(64, 64)), nn.Parameter(torch.zeros(128, 64))]
+    rows, total = rowmlp._step_rows(ws, 64, 0, False, 8)
+    assert total == L.pcb_mlp_stack_wbuf_elems(3, _desc([64, 64, 128], 0, gathered=True), 0, 0) == 2 * (64 * 64 + 128 * 64)
+
+
+def test_gradient_scratch_sizing(lib):
+    """pcb_mlp_stack_dzbuf_elems: two ping-pong slots of the widest inner gradient; a top layer whose dy is written
+    out once (bf16 rows, C > 256, more than 256 inputs, no pooling) widens them / makes them exist for one layer."""
+    L = lib.load()
+    R = 1000
+    assert L.pcb_mlp_stack_dzbuf_elems(0, 3, _desc([64, 64, 128], 8), R, 8, 0, 0) == 2 * R * 64
+    assert L.pcb_mlp_stack_dzbuf_elems(0, 1, _desc([128], 264), R, 264, 0, 0) == 0
+    assert L.pcb_mlp_stack_dzbuf_elems(0, 1, _desc([384], 264), R, 264, 0, 0) == 2 * R * 384      # dy slot for the single layer
+    assert L.pcb_mlp_stack_dzbuf_elems(0, 2, _desc([512, 320], 384), R, 384, 0, 0) == 2 * R * 512  # inner 512 (in place), top 320
+    assert L.pcb_mlp_stack_dzbuf_elems(0, 2, _desc([256, 512], 384), R, 384, 0, 0) == 2 * R * 384  # top: 256 inputs only -> not written out
+    assert L.pcb_mlp_stack_dzbuf_elems(0, 2, _desc([320, 512], 384), R, 384, 0, 0) == 2 * R * 512  # top written out
+    assert L.pcb_mlp_stack_dzbuf_elems(0, 2, _desc([320, 512], 384), R, 384, 16, 0) == 2 * R * 384  # pooled top: never
+    assert L.pcb_mlp_stack_dzbuf_elems(1, 2, _desc([320, 512], 384), R, 384, 0, 0) == 2 * R * 384   # fp32 rows: never
+
+
+def test_cross_entropy_on_cpu_is_the_reference_call(lib):
+    """losses.cross_entropy: CPU logits (the harness tests, the CPU port) take F.cross_entropy, the trainers' own call."""
+    import torch.nn.functional as F
+    from pointcloud_bridge_amd.losses import cross_entropy
+    torch.manual_seed(0)
+    logits = torch.randn(2, 5, 64, requires_grad=True)
+    labels = torch.randint(0, 5, (2, 64))
+    labels[0, :3] = -100
+    a = cross_entropy(logits, labels)
+    assert torch.equal(a, F.cross_entropy(logits, labels))
+    b = cross_entropy(logits.transpose(1, 2), labels, channels_last=True)
+    assert torch.allclose(a, b)
+
+
 def test_ops_refuse_cpu_tensors(lib):
     from pointcloud_bridge_amd import ops
     xyz = torch.rand(1, 16, 3)
