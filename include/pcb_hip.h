@@ -722,6 +722,12 @@ int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *
 int pcb_pad_rows_bf16(const float *x, long ld, long R, int k, int kp, void *out, void *stream);
 int pcb_pad_rows_f32(const float *x, long ld, long R, int k, int kp, void *out, void *stream);
 
+/* Many device-to-device copies in one launch: table in DEVICE memory, n rows of 4 int64 {dst, src, bytes (multiple of
+ * 4; addresses 4-byte aligned), first workgroup}; a copy takes ceil(bytes / 16384) workgroups, rows in ascending order,
+ * `blocks` = their total.  (The captured training step hands the next step's sampling results from its staging to its
+ * live buffers with it: StaticSampling.commit.) */
+int pcb_copy_table(const long long *table, int n, long blocks, void *stream);
+
 /*
  * Per-point cross entropy of the segmentation trainers (`criterion = nn.CrossEntropyLoss()` on [B,C,N]
  * logits vs [B,N] labels, train_MulSca_PN2.py:161; on [B*N,C] in train_DGCNN.py:177-197), mean over the

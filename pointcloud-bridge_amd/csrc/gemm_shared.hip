@@ -459,6 +459,39 @@ int pcb_zero2_async(void *a, size_t bytes_a, void *b, size_t bytes_b, hipStream_
     return pcb_check_launch();
 }
 
+// Many device-to-device copies in one launch: table (device memory) = n rows of 4 int64 {dst, src, bytes, first
+// workgroup}; a workgroup moves 16 KB (bisection over the rows as in prep_weights_table_kernel).  The captured
+// step's staging -> live hand-over of the sampling results was 24 copy nodes at the top of every replay.
+static __global__ __launch_bounds__(256) void copy_table_kernel(const long long *__restrict__ table, int n)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[4L * mid + 3] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long *d = table + 4L * lo;
+    char *const dst = reinterpret_cast<char *>(static_cast<uintptr_t>(d[0]));
+    const char *const src = reinterpret_cast<const char *>(static_cast<uintptr_t>(d[1]));
+    const long bytes = (long)d[2];
+    const long base = ((long)blockIdx.x - (long)d[3]) * 16384;
+    const long end = base + 16384 < bytes ? base + 16384 : bytes;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        for (long o = base + 16L * threadIdx.x; o + 16 <= end; o += 16 * 256)
+            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
+        for (long o = base + ((end - base) & ~15L) + 4L * threadIdx.x; o + 4 <= end; o += 4 * 256)
+            *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
+    } else {
+        for (long o = base + 4L * threadIdx.x; o + 4 <= end; o += 4 * 256)
+            *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
+    }
+}
+extern "C" int pcb_copy_table(const long long *table, int n, long blocks, void *stream)
+{
+    if (!table || n < 1 || blocks < 1 || blocks > 0x7fffffffL) return PCB_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(copy_table_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, n);
+    return pcb_check_launch();
+}
+
 int pcb_copy_async(void *dst, const void *src, size_t bytes, hipStream_t st)
 {
     if (!dst || !src || (bytes & 3)) return PCB_ERR_INVALID_ARG;

@@ -258,13 +258,28 @@ class StaticSampling:
                 self._stage(("csr", fine, coarse, int(k)), rowmlp.build_interp_csr(nn_res[1], clouds[coarse].shape[1]))
 
     def commit(self):
-        """staging -> live (capturable; the first operation of a captured step)."""
+        """staging -> live (capturable; the first operation of a captured step): ONE launch that walks a table of
+        all (live, staging) pairs -- two dozen copy nodes at the top of every replay otherwise.  The table is built
+        at the first call after the buffers exist (the eager warm-up steps, outside any capture)."""
+        pairs = []
         for lv in self.levels:
-            lv["idx"].copy_(lv["idx_s"])
-            lv["new_xyz"].copy_(lv["new_xyz_s"])
+            pairs += [(lv["idx"], lv["idx_s"]), (lv["new_xyz"], lv["new_xyz_s"])]
         for live, staged in self.extra.values():
-            for d, r in zip(live, staged):
-                d.copy_(r)
+            pairs += list(zip(live, staged))
+        sig = tuple((d.data_ptr(), r.data_ptr(), d.numel() * d.element_size()) for d, r in pairs)
+        if getattr(self, "_commit_sig", None) != sig:
+            if torch.cuda.is_current_stream_capturing():
+                for d, r in pairs:        # (a buffer appeared during the capture itself: plain copies)
+                    d.copy_(r)
+                return
+            vals, blocks = [], 0
+            for dptr, rptr, nbytes in sig:
+                vals += [dptr, rptr, nbytes, blocks]
+                blocks += (nbytes + 16383) // 16384
+            self._commit_table = torch.tensor(vals, dtype=torch.int64, device=pairs[0][0].device)
+            self._commit_sig, self._commit_blocks = sig, blocks
+        with ops.on_device(pairs[0][0].device):
+            ops._launch("pcb_copy_table", len(pairs), self._commit_table.data_ptr(), len(pairs), self._commit_blocks)
 
     def _level_of(self, t):
         """0 for a level-0 cloud (any tensor of the input size), l for the live coordinates of level l, else None."""
