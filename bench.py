@@ -665,6 +665,8 @@ def extras(args, device):
     out = {}
     plan = [
         ("pn2_msg_bridge_like_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, family="bridge")),
+        # the same clouds through the captured step (what --exec auto runs where the host is the bound)
+        ("pn2_msg_bridge_like_graph_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, family="bridge", graph=True)),
         ("pn2_msg_graph_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, graph=True)),
         ("pn2_msg_fp32_B16_N16384", dict(model_name="pn2_msg", precision="fp32", B=16, N=16384)),
         ("dgcnn_k20_B8_N8192_bf16", dict(model_name="dgcnn", precision="bf16", B=8, N=8192)),
