@@ -466,8 +466,9 @@ int pcb_bn_bwd_finalize(float *sums, int nparts, long rows, int C, const float *
 
 /* GEMM operands of n <= 8 layers from their fp32 master weights, in one launch
  * (replaces weight.view(Cout,Cin).to(bf16) / F.pad / .t().contiguous() per layer).
- * desc = n x 8 int64 on the HOST: {w fp32 [C,k], wp [C,kp], wt [kp,C] or 0, C, k, kp, perm, 0}; wp, wt
- * in the row type of the entry point.
+ * desc = n x 8 int64 on the HOST: {w fp32 [C,k], wp [C,kp], wt [kp,C] or 0, C, k, kp, perm, ldw}; wp, wt
+ * in the row type of the entry point; ldw = floats between the rows of w (0 = k; larger: w is a column slice of a
+ * wider parameter, read in place).
  * perm names the column layout of the layer's input rows: 0 = real columns in place, zero padded;
  * C > 0 = pcb_group_rows_* rows (C feature columns, then the 3 centred coordinates);
  * -D < 0 = interpolate+concat rows (first D columns in place, the rest from column pad(D)). */

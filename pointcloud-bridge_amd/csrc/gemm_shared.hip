@@ -266,10 +266,10 @@ long grid_knob(const char *name, long def)
 // (real_column) and, for the input-gradient GEMM, its transpose wt [kp, C].
 constexpr int PREP_MAX = 8;
 struct PrepLayer {
-    const float *w;   // [C, k] fp32
+    const float *w;   // [C, k] fp32, rows ldw floats apart (a column slice of a wider parameter: ldw > k)
     void *wp;         // [C, kp]
     void *wt;         // [kp, C] or NULL
-    int C, k, kp, perm;
+    int C, k, kp, perm, ldw;
 };
 struct PrepArgs {
     PrepLayer l[PREP_MAX];
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs args)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int c = e / L.kp, j = e - c * L.kp;
         const int r = real_column(j, L.k, L.perm, RowVec<T>::E);
-        const T h = to_elem<T>(r >= 0 ? L.w[(long)c * L.k + r] : 0.0f);
+        const T h = to_elem<T>(r >= 0 ? L.w[(long)c * L.ldw + r] : 0.0f);
         wp[e] = h;
         if (wt) wt[(long)j * L.C + c] = h;
     }
@@ -319,7 +319,8 @@ int prep_weights(int n, const long long *desc, float *zero, long zero_n, void *s
         a.l[i].k = (int)d[4];
         a.l[i].kp = (int)d[5];
         a.l[i].perm = (int)d[6];
-        if (!a.l[i].w || !a.l[i].wp || a.l[i].C <= 0 || a.l[i].k <= 0 || a.l[i].kp < a.l[i].k) return PCB_ERR_INVALID_ARG;
+        a.l[i].ldw = d[7] > 0 ? (int)d[7] : (int)d[4];   // slot [7]: row stride of w in floats (0 = k)
+        if (!a.l[i].w || !a.l[i].wp || a.l[i].C <= 0 || a.l[i].k <= 0 || a.l[i].kp < a.l[i].k || a.l[i].ldw < a.l[i].k) return PCB_ERR_INVALID_ARG;
         if (a.l[i].C * a.l[i].kp > most) most = a.l[i].C * a.l[i].kp;
     }
     int gx = (most + 255) / 256;

@@ -528,7 +528,9 @@ class _PointLinear(torch.autograd.Function):
         wp = torch.empty(C, K, dtype=torch.bfloat16, device=dev)
         wt = torch.empty(K, C, dtype=torch.bfloat16, device=dev) if x.requires_grad else None
         out = torch.empty(n, C, dtype=torch.float32, device=dev)
-        desc = (ctypes.c_longlong * 8)(w.data_ptr(), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), C, K, K, 0, 0)
+        if w.dtype != torch.float32 or w.stride(1) != 1 or w.shape[1] != K or w.stride(0) < K:
+            raise TypeError("point_linear expects an fp32 weight [C, K] with contiguous rows (a column slice of a wider weight is fine)")
+        desc = (ctypes.c_longlong * 8)(w.data_ptr(), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), C, K, K, 0, w.stride(0))
         with on_device(dev):
             _launch("pcb_prep_weights_bf16", C * K, 1, desc)
             _launch("pcb_gemm_nt_f32out_bf16", n * (K + 2 * C), x.data_ptr(), wp.data_ptr(), n, C, K, out.data_ptr())
@@ -559,14 +561,16 @@ class _PointLinear(torch.autograd.Function):
 
 
 class _SplitCols(torch.autograd.Function):
-    """w[:, :d] and w[:, d:] as two contiguous tensors.  Backward is ONE concatenation: a pair of plain
+    """w[:, :d] and w[:, d:] (views of w, rows w.shape[1] floats apart).  Backward is ONE concatenation: a pair of plain
     slices costs a zero fill, a copy and an accumulation per piece in the autograd engine (six launches
     for a weight the GEMMs read in two parts)."""
 
     @staticmethod
     def forward(ctx, w, d):
         ctx.d, ctx.shape = d, w.shape
-        return w[:, :d].contiguous(), w[:, d:].contiguous()
+        # views: the consumers (pcb_prep_weights_* through point_linear, the coordinate term of pcb_gather_add_bf16)
+        # read a column slice in place through its row stride -- two copy launches per gathered stack otherwise
+        return w[:, :d], w[:, d:]
 
     @staticmethod
     def backward(ctx, ga, gb):
@@ -580,7 +584,7 @@ class _SplitCols(torch.autograd.Function):
 
 
 def split_cols(w, d):
-    """(w[:, :d], w[:, d:]) of a 2-D weight, contiguous, with a single-launch backward (see _SplitCols)."""
+    """(w[:, :d], w[:, d:]) of a 2-D weight as views, with a single-launch backward (see _SplitCols)."""
     return _SplitCols.apply(w, int(d))
 
 
@@ -639,7 +643,7 @@ class _GatheredStack(torch.autograd.Function):
         gather = (ctypes.c_longlong * 12)(
             u.data_ptr(), 0 if v is None else v.data_ptr(), idx.data_ptr(), B, N, S, ns,
             0 if wx is None else xyz.data_ptr(), 0 if wx is None else ctr.data_ptr(),
-            0 if wx is None else wx.data_ptr(), 3, 0)
+            0 if wx is None else wx.data_ptr(), 3 if wx is None else wx.stride(0), 0)
         C = widths[-1]
         if pool:
             out = torch.empty(R // pool, C, dtype=torch.bfloat16, device=dev)
@@ -730,7 +734,7 @@ def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0, wx=None, xyz=None,
     for i, (conv, bn) in enumerate(zip(convs, bns)):
         flat += _layer_args(conv, bn, with_weight=bool(i))
     return _GatheredStack.apply(u.contiguous(), None if v is None else v.contiguous(),
-                                None if wx is None else wx.contiguous(),
+                                wx,
                                 None if wx is None else xyz.contiguous(), None if wx is None else ctr.contiguous(),
                                 idx.contiguous(), ns, act, pool, len(convs), *flat)
 
