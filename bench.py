@@ -669,6 +669,8 @@ def extras(args, device):
         ("pn2_msg_bridge_like_graph_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, family="bridge", graph=True)),
         ("pn2_msg_graph_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, graph=True)),
         ("pn2_msg_fp32_B16_N16384", dict(model_name="pn2_msg", precision="fp32", B=16, N=16384)),
+        # the single-scale network the reference publishes its own numbers on (models/pointnet2.py), captured step
+        ("pn2_ssg_graph_B16_N16384_bf16", dict(model_name="pn2_ssg", precision="bf16", B=16, N=16384, graph=True)),
         ("dgcnn_k20_B8_N8192_bf16", dict(model_name="dgcnn", precision="bf16", B=8, N=8192)),
         ("bridgeseg_B16_N16384_bf16", dict(model_name="bridgeseg", precision="bf16", B=16, N=16384)),
         ("pn2_msg_infer_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, mode="infer")),
