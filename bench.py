@@ -164,6 +164,9 @@ class Run:
                     m.p = 0.0
         self.model = model
         self.use_graph = mode == "train" and graph
+        # inference through one captured hipGraph per batch (pn2_msg / pn2_ssg: the eager eval pass is bound by the
+        # host -- ~160 launches, 2.4-2.8 ms of enqueueing against 2.6 ms of GPU time)
+        self.infer_graph = mode == "infer" and graph and hasattr(model, "static_sampling") and model_name in ("pn2_msg", "pn2_ssg")
         if self.use_graph and (model_name == "bridgeseg" or loss == "bridge"):
             # The narrow encoder layers of BridgeSeg and BridgeStructureLoss still run ATen BatchNorm /
             # reductions.  ATen's two-stage reductions (staging buffer + semaphores) return garbage on every
@@ -205,6 +208,8 @@ class Run:
             model.eval()
         if self.use_graph:
             self._capture()
+        if self.infer_graph:
+            self._capture_infer()
 
     # -- steps ------------------------------------------------------------------------------------
     def _batch(self, k=0):
@@ -226,6 +231,8 @@ class Run:
         return loss
 
     def infer_step(self):
+        if self.infer_graph:
+            return self.graph_infer_step()
         batch = self._batch()
         with torch.no_grad():
             if self.prefetch and hasattr(self.model, "set_next"):
@@ -233,6 +240,59 @@ class Run:
             loss = self.loss_of(self.model(batch[0], batch[1]), batch)
         self.i += 1
         return loss
+
+    def _capture_infer(self):
+        """The eval-mode forward pass (+ loss) of one batch as ONE hipGraph; the sampling pyramid, ball queries and
+        decoder k-NN of the NEXT batch run inside it on a forked stream, into the staging set the next replay
+        commits.  FPS start indices are drawn on the host before every replay (StaticSampling.draw), as in the
+        captured training step."""
+        from pointcloud_bridge_amd.models import pointnet2_utils as pu
+        model = self.model
+        xyz, colors, labels = (t.clone() for t in self.batches[0])
+        xyz_next = xyz.clone()
+        batch = (xyz, colors, labels)
+        static = model.static_sampling(xyz)
+        pu.set_static_sampling(static)
+        loss_buf = torch.zeros((), device=self.device)
+
+        def fwd():
+            with torch.no_grad():
+                static.commit()
+                # forked at the TOP of the pass: its chain (three FPS levels, ball queries, k-NN: ~2 ms on one stream) is
+                # longer than the decoder, and a captured pass must join it before it ends -- forked behind the encoder
+                # (what the eager pipeline does via model.set_next) it was the critical path: 3.16 ms against 2.61
+                static.compute_beside(xyz_next, calls=12)
+                self.logits_out = model(xyz, colors)     # (captured: the replay's output lives in the graph's pool)
+                loss = self.loss_of(self.logits_out, batch)
+                static.join()
+                loss_buf.copy_(loss)
+
+        with torch.no_grad():
+            static.draw()
+            static.compute(xyz_next)              # what the first pass commits
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(3):                    # eager warm-up on the capture stream (fills the eval operand cache)
+                static.draw()
+                fwd()
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        static.draw()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            fwd()
+
+        def graph_infer_step():
+            cur, nxt = self._batch(), self._batch(1)
+            xyz.copy_(cur[0]); colors.copy_(cur[1]); labels.copy_(cur[2])
+            xyz_next.copy_(nxt[0])
+            self.i += 1
+            static.draw()
+            graph.replay()
+            return loss_buf
+
+        self.graph_infer_step, self.static = graph_infer_step, static
 
     def _capture(self):
         """Forward + loss + backward (+ the next step's sampling pyramid on a forked stream) replayed as
@@ -440,7 +500,7 @@ class Run:
 
     def close(self):
         from pointcloud_bridge_amd.models import pointnet2_utils as pu
-        if self.use_graph:
+        if self.use_graph or self.infer_graph:
             pu.set_static_sampling(None)
         pu.set_scene_shard(0, 1)
         if hasattr(self.bucket, "close"):
@@ -517,6 +577,8 @@ def main():
     probes = {}
     can_graph = (args.mode == "train" and args.model in ("pn2_msg", "pn2_ssg", "dgcnn") and args.loss == "ce"
                  and not args.dump and not args.no_prefetch)
+    if exec_mode == "auto" and args.mode == "infer" and args.model in ("pn2_msg", "pn2_ssg") and not args.no_prefetch:
+        exec_mode = "graph"     # the eval pass is host-bound when launched kernel by kernel (2.77 vs 2.61 ms captured)
     if exec_mode == "auto" and not can_graph:
         exec_mode = "eager"
     run = None
@@ -674,6 +736,7 @@ def extras(args, device):
         ("dgcnn_k20_B8_N8192_bf16", dict(model_name="dgcnn", precision="bf16", B=8, N=8192)),
         ("bridgeseg_B16_N16384_bf16", dict(model_name="bridgeseg", precision="bf16", B=16, N=16384)),
         ("pn2_msg_infer_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, mode="infer")),
+        ("pn2_msg_infer_graph_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, mode="infer", graph=True)),
         # cfg5 as the reference runs it (inference_ptv3.py:48-51, :101-105) and on tiles of 16384 points
         ("ptv3_infer_B8_N4096_bf16", dict(model_name="ptv3", precision="bf16", B=8, N=4096, mode="infer")),
         ("ptv3_infer_B2_N16384_bf16", dict(model_name="ptv3", precision="bf16", B=2, N=16384, mode="infer")),

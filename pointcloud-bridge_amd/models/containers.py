@@ -50,7 +50,11 @@ class _SamplingPrefetchMixin:
     def _start_next(self):
         if self._next_xyz is not None:
             nxt, self._next_xyz = self._next_xyz, None
-            self.prefetch(nxt)
+            from . import pointnet2_utils as pu
+            if pu._static is not None:      # a captured pass: into the pipeline's staging set, on its side stream
+                pu._static.compute_beside(nxt.contiguous())
+            else:
+                self.prefetch(nxt)
 
 
 # (npoint, radius, nsample, in_channel, mlp) -- models/model.py:17-19 == models/pointnet2.py:20-22

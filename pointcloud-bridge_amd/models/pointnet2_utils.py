@@ -257,6 +257,23 @@ class StaticSampling:
             if torch.is_grad_enabled():
                 self._stage(("csr", fine, coarse, int(k)), rowmlp.build_interp_csr(nn_res[1], clouds[coarse].shape[1]))
 
+    def compute_beside(self, xyz, calls=1 << 30):
+        """compute(xyz) on this pipeline's own side stream, forked from the current stream (pipelined inference
+        inside a captured pass: the next batch's sampling beside the decoder); join() brings it back.  The forward
+        stacks that follow leave the pyramid's CUs alone (ops.set_background_work)."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self.compute(xyz)
+        self._forked = True
+        ops.set_background_work(torch.cuda.Event(), 2 * xyz.shape[0], calls=calls)
+
+    def join(self):
+        if getattr(self, "_forked", False):
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._forked = False
+
     def commit(self):
         """staging -> live (capturable; the first operation of a captured step): ONE launch that walks a table of
         all (live, staging) pairs -- two dozen copy nodes at the top of every replay otherwise.  The table is built

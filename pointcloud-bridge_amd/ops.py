@@ -83,12 +83,15 @@ _background = None  # (event, busy_cus)
 _hint_now = 0
 _capture_calls = 0
 _GRAPH_HINT_CALLS = int(os.environ.get("PCB_GRAPH_HINT_CALLS", "8"))
+_capture_limit = _GRAPH_HINT_CALLS
 
 
-def set_background_work(event, busy_cus):
-    global _background, _capture_calls
+def set_background_work(event, busy_cus, calls=None):
+    """calls: inside a capture, how many stack calls from here on keep the hint (default PCB_GRAPH_HINT_CALLS)."""
+    global _background, _capture_calls, _capture_limit
     _background = (event, int(busy_cus))
     _capture_calls = 0
+    _capture_limit = _GRAPH_HINT_CALLS if calls is None else int(calls)
 
 
 def apply_concurrency_hint():
@@ -104,7 +107,7 @@ def apply_concurrency_hint():
             # n = 0 / 4 / 8 / 12 / 20: 7.63 / 7.59 / 7.46 / 7.47 / 7.57 ms per step (PCB_GRAPH_HINT_CALLS, default 8).
             global _capture_calls
             _capture_calls += 1
-            want = _background[1] if _capture_calls <= _GRAPH_HINT_CALLS else 0
+            want = _background[1] if _capture_calls <= _capture_limit else 0
         elif _background[0].query():
             _background = None          # finished: the GPU is ours again
         else:

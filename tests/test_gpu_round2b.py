@@ -240,3 +240,38 @@ def test_prepare_step_changes_nothing_but_the_launch_count(precision):
     finally:
         rowmlp.set_step_operands(True)
         rowmlp.set_precision("fp32")
+
+
+def test_captured_inference_pass_equals_the_eager_pass(monkeypatch):
+    """bench.py --mode infer --exec graph: the eval forward pass of a batch replayed from one hipGraph, the NEXT batch's
+    sampling pyramid / ball queries / k-NN computed inside it on a forked stream into the staging set the next replay
+    commits.  With the FPS start indices pinned (torch.randint -> zeros) every replay's logits must equal the plain
+    eager pass over the same batch bit for bit -- three consecutive batches, i.e. two hand-overs of the double set."""
+    import argparse
+    import bench
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models import pointnet2_utils as pu
+    real_randint = torch.randint
+
+    def zeros_on_cpu(*a, **k):
+        out = real_randint(*a, **k)
+        return out.zero_() if out.device.type == "cpu" else out
+
+    monkeypatch.setattr(torch, "randint", zeros_on_cpu)
+    args = argparse.Namespace(no_dropout=True, no_prefetch=False, dump=False)
+    run = bench.Run(args, "pn2_msg", "bf16", 4, 4096, 0, 1, torch.device("cuda", 0), mode="infer", graph=True)
+    try:
+        for step in range(3):
+            batch = run._batch()
+            run.infer_step()
+            torch.cuda.synchronize()
+            got = run.logits_out.clone()
+            pu.set_static_sampling(None)
+            with torch.no_grad():
+                want = run.model(batch[0], batch[1])
+            pu.set_static_sampling(run.static)
+            assert torch.equal(got, want), (step, float((got - want).abs().max()))
+    finally:
+        run.close()
+        pu.set_static_sampling(None)
+        rowmlp.set_precision("fp32")
