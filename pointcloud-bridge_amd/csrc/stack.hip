@@ -429,7 +429,7 @@ extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, co
     // stz is cleared by the first weight-preparation launch (or a zero launch if there is none).  What needs clearing is
     // the single accumulation slab of a backward reduction without slabs (rows 6, 7); with a slab buffer every row of
     // stz is written before it is read, so a call with prepared weights and `parts` clears nothing.
-    bool cleared = ready || (wready && parts);
+    bool cleared = ready || (wready && parts && parts_slabs > 1);
 
     // GEMM operands of all layers (chunks of 8 layers per launch)
     for (int l0 = gathered ? 1 : 0; l0 < L && !ready && !wready; l0 += 8) {
