@@ -309,15 +309,36 @@ __global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const T *__res
         float acc[E];
 #pragma unroll
         for (int i = 0; i < E; ++i) acc[i] = 0.0f;
-        for (long e = beg + half; e < end; e += 2) {
-            const int ent = entries[e];
-            const long n = ent / K;
-            const float wt = w[(b * N + n) * K + (ent - (int)n * K)];
-            if (c < C) {
-                float f[E];
-                RowVec<T>::unpack(*reinterpret_cast<const uint4 *>(g + (b * N + n) * (long)ld + col0 + c), f);
+        // four entries per half-wave and step: their index, weight and row loads are issued together (one entry per
+        // step made every row load wait for its own index load: a chain of two memory latencies per entry), the
+        // products are added in entry order as before
+        const int cs = c < C ? c : 0;
+        for (long e0 = beg + half; e0 < end; e0 += 8) {
+            int ent[4];
+            long row[4];
+            float wt[4];
+            uint4 v[4];
 #pragma unroll
-                for (int i = 0; i < E; ++i) acc[i] = fmaf(f[i], wt, acc[i]);
+            for (int u = 0; u < 4; ++u) {
+                const long e = e0 + 2 * u < end ? e0 + 2 * u : beg;     // (beg: a valid entry, masked below)
+                ent[u] = entries[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long n = ent[u] / K;
+                row[u] = b * N + n;
+                wt[u] = w[row[u] * K + (ent[u] - (int)n * K)];
+                v[u] = *reinterpret_cast<const uint4 *>(g + row[u] * (long)ld + col0 + cs);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e0 + 2 * u >= end) break;
+                if (c < C) {
+                    float f[E];
+                    RowVec<T>::unpack(v[u], f);
+#pragma unroll
+                    for (int i = 0; i < E; ++i) acc[i] = fmaf(f[i], wt[u], acc[i]);
+                }
             }
         }
 #pragma unroll
