@@ -86,10 +86,11 @@ def test_bwd_reduce_slabs(sfx, dtype, R, C):
               R, C, 1, sums.data_ptr(), 769, _stream()) < 0  # more slabs than the library ever writes
 
 
-@pytest.mark.parametrize("R,M,N", [(8192, 1536, 1024), (262144, 64, 64)])
+@pytest.mark.parametrize("R,M,N", [(8192, 1536, 1024), (262144, 64, 64), (131072, 256, 264)])
 def test_weight_gradient_slab_sums(R, M, N):
-    """dW = dy^T x through pcb_gemm_tn_bf16: few slabs of a large matrix (first shape) and hundreds of slabs of a
-    small one (second) take different paths of the slab-sum kernel; both against an fp64 product."""
+    """dW = dy^T x through pcb_gemm_tn_bf16: few slabs of a large matrix (first shape), hundreds of slabs of a small
+    one (second) and many slabs of a large one (third: 16-byte loads) take different paths of the slab-sum kernel; all
+    against an fp64 product."""
     from pointcloud_bridge_amd import _lib
     lib = _lib.load()
     torch.manual_seed(6)
@@ -275,3 +276,28 @@ def test_captured_inference_pass_equals_the_eager_pass(monkeypatch):
         run.close()
         pu.set_static_sampling(None)
         rowmlp.set_precision("fp32")
+
+
+def test_copy_table_moves_every_buffer():
+    """pcb_copy_table: many device-to-device copies from one launch (the captured steps' staging -> live hand-over):
+    buffers of different dtypes and sizes, one of them not 16-byte aligned, bytes beyond each buffer untouched."""
+    from pointcloud_bridge_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(8)
+    srcs = [torch.randint(0, 1 << 40, (16, 1024), device="cuda"), torch.randn(16, 512, 3, device="cuda"),
+            torch.randn(100003, device="cuda")[1:], torch.randint(0, 100, (7,), device="cuda", dtype=torch.int32),
+            torch.randn(5_000_000, device="cuda")]
+    dsts = [torch.full_like(t, 3) for t in srcs]
+    guard = [torch.full((t.numel() + 8,), 7, dtype=t.dtype, device="cuda") for t in srcs]   # copies land in the middle
+    dsts = [g[4:4 + t.numel()].view(t.shape) for g, t in zip(guard, srcs)]
+    vals, blocks = [], 0
+    for d, r in zip(dsts, srcs):
+        nbytes = r.numel() * r.element_size()
+        vals += [d.data_ptr(), r.data_ptr(), nbytes, blocks]
+        blocks += (nbytes + 16383) // 16384
+    table = torch.tensor(vals, dtype=torch.int64, device="cuda")
+    assert lib.pcb_copy_table(table.data_ptr(), len(srcs), blocks, _stream()) == 0
+    torch.cuda.synchronize()
+    for g, d, r in zip(guard, dsts, srcs):
+        assert torch.equal(d, r)
+        assert bool((g[:4] == 7).all()) and bool((g[-4:] == 7).all())
