@@ -406,6 +406,10 @@ int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *bias, long 
                           void *stream);
 int pcb_gemm_nt_bias_f32(const void *a, const void *w, const float *bias, long R, int N, int K, void *out,
                          void *stream);
+/* pcb_gemm_nt_bias_bf16 whose epilogue also adds the bf16 rows res [R,N] to the rounded result: x = trunk + boundary
+ * term of EnhancedFeaturePropagation.forward (models/pointnet2_utils.py:296) without an addition pass. */
+int pcb_gemm_nt_bias_add_bf16(const void *a, const void *w, const float *bias, const void *res, long R, int N, int K,
+                              void *out, void *stream);
 int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
                               void *wp, void *wt, float *bp, void *stream);
 int pcb_prep_linear_bias_f32(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,

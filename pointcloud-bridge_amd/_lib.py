@@ -48,6 +48,7 @@ SIGNATURES = {
     "pcb_gemm_nt_partials": [_i, _l, _i],
     "pcb_gemm_nt_bias_bf16": [_p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_gemm_nt_bias_f32": [_p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_gemm_nt_bias_add_bf16": [_p, _p, _p, _p, _l, _i, _i, _p, _p],
     "pcb_prep_linear_bias_bf16": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "pcb_prep_linear_bias_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "pcb_gemm_nt_f32out_bf16": [_p, _p, _l, _i, _i, _p, _p],

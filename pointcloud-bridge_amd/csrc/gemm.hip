@@ -219,6 +219,7 @@ struct RedArgs {
     const float *scale, *shift, *mean, *invstd;  // its per-column constants
     int act;
     const float *bias;  // plain epilogue only (no STATS, no RED): out = A'.W^T + bias[N] (a conv without BatchNorm)
+    const u16 *res;     // ... + res[R, N] (bf16 rows, added to the rounded result: the sum of two branches' outputs)
 };
 
 template <int PRO, int STATS, int RED, int OUT32 = 0>
@@ -725,8 +726,17 @@ __global__ __launch_bounds__(WM * 128, OCC) void gemm_nt8_kernel(Operand A_arg, 
             const int rr = ch >> 3, cc = (ch & 7) * 8;
             const long r = m0 + wm * 32 + rr;
             const int n = n0 + wn * 64 + cc;
-            const uint4 o = *reinterpret_cast<const uint4 *>(&stg[rr * OLD + cc]);
+            uint4 o = *reinterpret_cast<const uint4 *>(&stg[rr * OLD + cc]);
             const int off = (r < R && n < N) ? (int)(((long)(wm * 32 + rr) * N + n) * 2) : -1;
+            if (!STATS && !RED && red_arg.res) {   // (wave-uniform) the other branch's rows, added to the rounded result
+                const uint4 rv = *reinterpret_cast<const uint4 *>(red_arg.res + (r < R ? r : R - 1) * N + (n < N ? n : 0));
+                float fo[8], fr[8];
+                unpack8(o, fo);
+                unpack8(rv, fr);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fo[i] += fr[i];
+                o = pack8(fo);
+            }
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{o.x, o.y, o.z, o.w}, orsrc, off, 0, 0);
             if (RED) {
                 float dz[8], yv[8];
@@ -1101,7 +1111,7 @@ void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, 
     // without, the resident-workgroup preference for the hint in force now
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)(sums ? nparts : pcb_nt_grid_x(PRO, R, N, pcb_busy_cus())), ny);
-    RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
     // the eight-wave form: its LDS constants limit K for the BatchNorm-on-load prologue only (plain rows: any K)
     if (PRO == PRO_PLAIN || (PRO == PRO_BNACT && K <= N8_MAXK)) {
         // forward prologues: the eight-wave form, two workgroups per CU
@@ -1244,7 +1254,7 @@ extern "C" int pcb_gemm_nt_f32out_bf16(const void *a, const void *w, long R, int
     const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)pcb_nt_grid_x(PRO_PLAIN, R, N, pcb_busy_cus()), ny);
-    const RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    const RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);
@@ -1264,7 +1274,7 @@ extern "C" int pcb_gemm_nt_bias_bf16(const void *a, const void *w, const float *
     const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)pcb_nt_grid_x(PRO_PLAIN, R, N, pcb_busy_cus()), ny);
-    const RedArgs epi = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, bias};
+    const RedArgs epi = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, bias, nullptr};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);
@@ -1302,6 +1312,27 @@ extern "C" int pcb_gemm_tn_bf16(int apro, const void *dz, const void *y, const f
     return pcb_check_launch();
 }
 
+// y = (x W^T + b) + res: the same, and the bf16 rows `res` [R, N] are added to the rounded result in the epilogue -- the
+// sum of two branches' outputs (EnhancedFeaturePropagation: trunk + boundary term, pointnet2_utils.py:296) without a
+// pass of its own.
+extern "C" int pcb_gemm_nt_bias_add_bf16(const void *a, const void *w, const float *bias, const void *res, long R, int N,
+                                         int K, void *out, void *stream)
+{
+    if (!a || !w || !out || !res || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
+    const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
+    const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
+    const dim3 grid((unsigned)pcb_nt_grid_x(PRO_PLAIN, R, N, pcb_busy_cus()), ny);
+    const RedArgs epi = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, bias, (const u16 *)res};
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
+    hipLaunchKernelGGL((gemm_nt8_kernel<PRO_PLAIN, 0, 0, 4, 4>), grid, dim3(512), 0, st, A, (const u16 *)w, R, N, K,
+                       (u16 *)out, (float *)nullptr, epi);
+    pcb_timer_end(st, timed, nt_bytes(PRO_PLAIN, R, N, K, 0) + 2.0 * R * N, PRO_PLAIN, R, N, K);
+    return pcb_check_launch();
+}
+
 // Weight AND bias gradient of a conv without BatchNorm in one pass over dy: dW = dy^T x, dbias = column sums of dy.
 extern "C" int pcb_gemm_tn_bias_bf16(const void *dy, const void *x, long R, int M, int N, float *workspace, float *dW,
                                      int out_cols, int out_perm, float *dbias, void *stream)
@@ -1335,7 +1366,7 @@ extern "C" int pcb_gemm_nt_red_bf16(int pro, const void *a0, const void *a1, con
     if (pro == PRO_DY_POOL && (!dout || !argmax || ns <= 0 || ns > 255)) return PCB_ERR_INVALID_ARG;
     if (N > NT_BN) return PCB_ERR_UNSUPPORTED;  // one column tile only (the caller checks N <= 128)
     const Operand A = make_operand(a0, a1, K, scale, shift, p, q, dout, argmax, ns, act);
-    const RedArgs red = {(const u16 *)red_y, red_scale, red_shift, red_mean, red_invstd, red_act, nullptr};
+    const RedArgs red = {(const u16 *)red_y, red_scale, red_shift, red_mean, red_invstd, red_act, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);

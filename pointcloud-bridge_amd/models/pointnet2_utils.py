@@ -689,8 +689,15 @@ class EnhancedFeaturePropagation(nn.Module):
                 y = y + rowmlp.ungap_rows(g, perm)                  # :292-293
             return y
 
-        # the boundary term depends on the coordinates only: its own stream beside the trunk
-        y, edge = run_branches(xyz1.device, [trunk, lambda: _seq_rows(self.boundary_aware, xyz1.reshape(B * N, 3))],
-                               inputs=(xyz1,))                       # :283
-        x = y + edge                                                # :296
+        # the boundary term depends on the coordinates only: all of it but its last conv runs on its own stream beside
+        # the trunk; that conv (no BatchNorm behind it) adds the trunk's rows in its epilogue -- x = trunk + edge (:296)
+        # without an addition pass
+        ba = list(self.boundary_aware)
+        if isinstance(ba[-1], (nn.Conv1d, nn.Conv2d)) and len(ba) >= 2:
+            y, h = run_branches(xyz1.device, [trunk, lambda: _seq_rows(ba[:-1], xyz1.reshape(B * N, 3))],
+                                inputs=(xyz1,))                      # :283
+            x = rowmlp.conv_rows(ba[-1], h, add=y)
+        else:
+            y, edge = run_branches(xyz1.device, [trunk, lambda: _seq_rows(ba, xyz1.reshape(B * N, 3))], inputs=(xyz1,))
+            x = y + edge
         return x.view(B, N, -1).transpose(1, 2)

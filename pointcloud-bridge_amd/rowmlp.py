@@ -847,10 +847,12 @@ class _LinearBias(torch.autograd.Function):
     gradient with the split-row MFMA kernel (fp32, no atomics), bias gradient as a column sum."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_gap, m):
+    def forward(ctx, x, weight, bias, out_gap, m, res=None):
         """out_gap = D > 0: the output keeps the interpolate_concat column layout (first D outputs
         in place, the rest from column pad(D); untouched columns are exactly zero) and is returned
-        with all its padded columns; out_gap = 0: plain [R, n] output."""
+        with all its padded columns; out_gap = 0: plain [R, n] output.
+        res (bf16 rows [R, n], n a multiple of 8, out_gap = 0): added to the rounded result in the GEMM's
+        epilogue -- the sum of two branches' outputs without an addition pass."""
         w = weight.reshape(weight.shape[0], -1)
         if not (w.is_contiguous() and w.dtype == torch.float32):
             raise TypeError("fused layers expect contiguous fp32 master weights")
@@ -873,12 +875,17 @@ class _LinearBias(torch.autograd.Function):
             if hit is None:
                 _launch("pcb_prep_linear_bias_" + m.sfx, npad * kp, w.data_ptr(), 0 if bias is None else bias.data_ptr(), n, k,
                         npad, kp, int(out_gap), wp.data_ptr(), 0 if wt is None else wt.data_ptr(), bp.data_ptr())
-            _launch("pcb_gemm_nt_bias_" + m.sfx, 2 * R * (npad + kp), x.data_ptr(), wp.data_ptr(), bp.data_ptr(), R, npad, kp,
-                    y.data_ptr())
+            if res is not None:
+                _launch("pcb_gemm_nt_bias_add_bf16", 2 * R * (2 * npad + kp), x.data_ptr(), wp.data_ptr(), bp.data_ptr(),
+                        res.data_ptr(), R, npad, kp, y.data_ptr())
+            else:
+                _launch("pcb_gemm_nt_bias_" + m.sfx, 2 * R * (npad + kp), x.data_ptr(), wp.data_ptr(), bp.data_ptr(), R, npad, kp,
+                        y.data_ptr())
         if cache_key is not None and hit is None:
             _eval_store(cache_key, weight, versions, (wp, wt, bp))
         ctx.save_for_backward(x, wt)
         ctx.cfg = (weight.shape, n, k, bias is not None, int(out_gap), npad, m)
+        ctx.has_res = res is not None
         return y if out_gap else y[:, :n]
 
     @staticmethod
@@ -911,17 +918,26 @@ class _LinearBias(torch.autograd.Function):
                 if has_bias:
                     _launch("pcb_colstats_" + m.sfx, R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
                     db = sums[0]
+        gres = g if ctx.has_res else None   # d(out)/d(res) = identity
         if not out_gap:
-            return dx, dw[:n].reshape(wshape), (db[:n].clone() if has_bias else None), None, None
+            return dx, dw[:n].reshape(wshape), (db[:n].clone() if has_bias else None), None, None, gres
         rows = _gap_row_index(n, out_gap, m.q, dev)
-        return dx, dw[rows].reshape(wshape), (db[rows] if has_bias else None), None, None
+        return dx, dw[rows].reshape(wshape), (db[rows] if has_bias else None), None, None, gres
 
 
-def conv_rows(conv, x, out_dtype=None, out_gap=0):
-    """Plain 1x1 conv (with bias) on rows, no BatchNorm; out_gap: see _LinearBias.forward."""
+def conv_rows(conv, x, out_dtype=None, out_gap=0, add=None):
+    """Plain 1x1 conv (with bias) on rows, no BatchNorm; out_gap: see _LinearBias.forward.
+    add: rows [R, n] to add to the result; bf16 rows of a width the engine takes go into the GEMM's epilogue."""
     m = mode()
     xr = _rows(x, m.pad(x.shape[1]), m)
-    y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m)
+    n = conv.out_channels
+    if (add is not None and m.sfx == "bf16" and not out_gap and n % m.q == 0 and add.dtype == m.dtype
+            and add.shape == (xr.shape[0], n) and add.is_contiguous()):
+        y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m, add)
+    else:
+        y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m)
+        if add is not None:
+            y = y + add
     return y if out_dtype is None else y.to(out_dtype)
 
 

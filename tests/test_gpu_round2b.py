@@ -301,3 +301,28 @@ def test_copy_table_moves_every_buffer():
     for g, d, r in zip(guard, dsts, srcs):
         assert torch.equal(d, r)
         assert bool((g[:4] == 7).all()) and bool((g[-4:] == 7).all())
+
+
+def test_conv_rows_with_the_other_branch_added_in_the_epilogue():
+    """conv_rows(conv, x, add=y): y = the other branch's bf16 rows, added to the rounded GEMM result in the epilogue
+    (EnhancedFeaturePropagation: trunk + boundary term, reference :296).  Equal to the separate addition, gradients
+    included (d/d(add) is the identity)."""
+    from pointcloud_bridge_amd import rowmlp
+    rowmlp.set_precision("bf16")
+    try:
+        torch.manual_seed(12)
+        conv = torch.nn.Conv1d(64, 128, 1).cuda()
+        x = torch.randn(5000, 64, device="cuda").to(torch.bfloat16).requires_grad_(True)
+        y = torch.randn(5000, 128, device="cuda").to(torch.bfloat16).requires_grad_(True)
+        g = torch.randn(5000, 128, device="cuda").to(torch.bfloat16)
+        out = rowmlp.conv_rows(conv, x, add=y)
+        out.backward(g)
+        got = (out.detach().clone(), x.grad.clone(), y.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+        x.grad = y.grad = conv.weight.grad = conv.bias.grad = None
+        ref = rowmlp.conv_rows(conv, x) + y
+        ref.backward(g)
+        assert torch.equal(got[0], ref.detach())          # bf16(bf16(x W^T + b) + y) both ways
+        assert torch.equal(got[1], x.grad) and torch.equal(got[2], y.grad) and torch.equal(got[2], g)
+        assert torch.equal(got[3], conv.weight.grad) and torch.equal(got[4], conv.bias.grad)
+    finally:
+        rowmlp.set_precision("fp32")
