@@ -410,6 +410,18 @@ int pcb_gemm_nt_bias_f32(const void *a, const void *w, const float *bias, long R
  * term of EnhancedFeaturePropagation.forward (models/pointnet2_utils.py:296) without an addition pass. */
 int pcb_gemm_nt_bias_add_bf16(const void *a, const void *w, const float *bias, const void *res, long R, int N, int K,
                               void *out, void *stream);
+/* The GEMM of a Conv+BatchNorm layer whose input is the concatenation [x | level1 | level2] with the coarse levels
+ * REPEATED 2^sh times along the rows -- MultiScaleFeatureFusion's nearest upsampling followed by final_fusion's first
+ * conv (models/model.py:150-170, :93-99) -- without the concatenated rows: the conv is linear, so the caller forms the
+ * coarse levels' share on their own rows (add_l = level_l W_l^T, fp32 [R >> sh_l, N]) and this entry computes
+ *   out = bf16(a W^T + add1[r >> sh1] + add2[r >> sh2])      (a [R,K] bf16, w [N,K] prepared, sh >= 2, add2 may be NULL)
+ * plus the batch statistics of out as slabs sums [nparts][2][N] (as pcb_gemm_nt_bf16 with sums).
+ * pcb_dy_repeat_sums_bf16 is its backward towards the addends: d add_l[i] = sum of dy over the 2^sh_l rows coarse row i
+ * stood for, dy rebuilt from (dz, y, BatchNorm-backward constants) as in pcb_dy_rows_bf16 (d2 may be NULL; sh2 >= sh1). */
+int pcb_gemm_nt_stats_add_bf16(const void *a, const void *w, long R, int N, int K, void *out, float *sums, int nparts,
+                               const float *add1, int sh1, const float *add2, int sh2, void *stream);
+int pcb_dy_repeat_sums_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *p,
+                            const float *q, int act, long R, int C, int sh1, float *d1, int sh2, float *d2, void *stream);
 int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
                               void *wp, void *wt, float *bp, void *stream);
 int pcb_prep_linear_bias_f32(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
@@ -644,6 +656,10 @@ int pcb_attention_fwd_bf16(const void *qkv, int B, int N, int H, int D, float sc
  *   [9] y [R,C]: the layer's pre-BatchNorm GEMM output (written by forward, read by backward)
  *   [10] dW fp32 [C,k]  [11] dgamma [C]  [12] dbeta [C]  [13] dbias [C]   (backward outputs, any may be 0)
  *   [14] num_batches_tracked (int64 scalar, forward: += 1) or 0
+ *   [15] layer 0 of a plain bf16 stack only, else 0: HOST address of 7 int64 --
+ *        {add1, sh1, add2 or 0, sh2, d add1, d add2, row stride of w in floats or 0}: the layer's GEMM is
+ *        pcb_gemm_nt_stats_add_bf16 (forward), backward also writes d add1 / d add2 where given
+ *        (pcb_dy_repeat_sums_bf16); w may be a column slice of a wider weight (its rows `stride` floats apart)
  * fdesc: L x 2 doubles: momentum, eps.  stat_repeat >= 1: every row of x stands for that many
  * identical samples (see pcb_bn_finalize `count`); 1 otherwise.
  * x [R,Kp] rows in the column layout `perm` (see pcb_prep_weights_*); act 0/1/2;

@@ -220,6 +220,13 @@ struct RedArgs {
     int act;
     const float *bias;  // plain epilogue only (no STATS, no RED): out = A'.W^T + bias[N] (a conv without BatchNorm)
     const u16 *res;     // ... + res[R, N] (bf16 rows, added to the rounded result: the sum of two branches' outputs)
+    // STATS == 2 (eight-wave form): out = A'.W^T + add1[r >> sh1, :] + add2[r >> sh2, :] before rounding -- fp32 rows
+    // [R >> sh, N], each standing for 2^sh consecutive output rows (sh >= 2; add2 optional).  The layer's input is the
+    // concatenation of a full-resolution level with coarser levels REPEATED along the rows
+    // (MultiScaleFeatureFusion, models/model.py:150-170): the conv is linear, so the coarse levels' share of the
+    // product is computed on their own rows and arrives here instead of as 2^sh copies in the A operand.
+    const float *add1, *add2;
+    int sh1, sh2;
 };
 
 template <int PRO, int STATS, int RED, int OUT32 = 0>
@@ -701,10 +708,24 @@ __global__ __launch_bounds__(WM * 128, OCC) void gemm_nt8_kernel(Operand A_arg, 
                 const int n = n0 + wn * 64 + j * 32 + (lane & 31);
                 bj = n < N ? red_arg.bias[n] : 0.0f;
             }
+            float ad[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (STATS == 2) {
+                // the lane's 16 accumulators are 4 runs of 4 consecutive rows (aligned to 4): one coarse row each
+                // (sh >= 2).  Rows past R take nothing: they must stay out of the statistics.
+                const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const long r = m0 + wm * 32 + 8 * g + 4 * (lane >> 5);
+                    if (r < R && n < N) {
+                        ad[g] = red_arg.add1[(r >> red_arg.sh1) * N + n];
+                        if (red_arg.add2) ad[g] += red_arg.add2[(r >> red_arg.sh2) * N + n];
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                const u16 h = f2bf((!STATS && !RED) ? acc[j][i] + bj : acc[j][i]);
+                const u16 h = f2bf((!STATS && !RED) ? acc[j][i] + bj : (STATS == 2 ? acc[j][i] + ad[i >> 2] : acc[j][i]));
                 stg[rr * OLD + j * 32 + (lane & 31)] = h;
                 if (STATS) {
                     const float v = bf2f(h);
@@ -1103,6 +1124,55 @@ __global__ __launch_bounds__(256) void dy_rows_kernel(Operand A_arg, long R, int
     }
 }
 
+// Gradient of the repeated addends of a STATS == 2 layer (RedArgs.add1 / add2): d add[i, :] = sum of dy over the 2^sh
+// consecutive rows coarse row i stood for.  One workgroup per coarse row of the COARSER level (2^sh2 rows, sh2 >= sh1);
+// a lane owns a 16-byte column chunk, RT = 256 / (C/8) lanes share the rows of a run, their partial sums meet in LDS.
+// dy = bf16(scale.dz.act' + p.y + q), the very values the layer's two gradient GEMMs rebuild in their prologues.
+__global__ __launch_bounds__(256) void dy_repeat_sums_kernel(Operand A_arg, long R, int C, int sh1, float *__restrict__ d1,
+                                                              int sh2, float *__restrict__ d2)
+{
+    __shared__ float red[2048];  // [RT][C] = 256 lanes x 8 columns
+    const Operand A = local_copy(A_arg);
+    const float slope = act_slope(A.act);
+    const int CT = C / 8, RT = 256 / CT;
+    const int cc = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const bool on = rl < RT;
+    Consts<PRO_DY> k;
+    k.load(A, cc * 8, C);
+    const long g1 = 1L << sh1, g2 = 1L << sh2;
+    const long base = (long)blockIdx.x * g2;
+    float tot = 0.0f;  // lanes t < C: column t of the coarser level's sum
+    for (long s = 0; s < g2; s += g1) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (on) {
+            for (long r0 = rl; r0 < g1; r0 += 2 * RT) {
+                Raw<PRO_DY> ra[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) ra[u].load(A, base + s + r0 + u * RT, cc * 8, R, C);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (r0 + u * RT >= g1 || base + s + r0 + u * RT >= R) continue;
+                    float f[8];
+                    unpack8(ra[u].finish(k, slope), f);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += f[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[rl * C + cc * 8 + i] = acc[i];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            float v = 0.0f;
+            for (int j = 0; j < RT; ++j) v += red[j * C + threadIdx.x];
+            if (base + s < R) d1[((base + s) >> sh1) * C + threadIdx.x] = v;
+            tot += v;
+        }
+        __syncthreads();
+    }
+    if (d2 && (int)threadIdx.x < C && base < R) d2[(base >> sh2) * C + threadIdx.x] = tot;
+}
+
 template <int PRO>
 void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, float *sums, int nparts, hipStream_t st,
                const RedArgs *red = nullptr)
@@ -1330,6 +1400,49 @@ extern "C" int pcb_gemm_nt_bias_add_bf16(const void *a, const void *w, const flo
     hipLaunchKernelGGL((gemm_nt8_kernel<PRO_PLAIN, 0, 0, 4, 4>), grid, dim3(512), 0, st, A, (const u16 *)w, R, N, K,
                        (u16 *)out, (float *)nullptr, epi);
     pcb_timer_end(st, timed, nt_bytes(PRO_PLAIN, R, N, K, 0) + 2.0 * R * N, PRO_PLAIN, R, N, K);
+    return pcb_check_launch();
+}
+
+// The GEMM of a BatchNorm layer whose input is [x | level1 repeated 2^sh1 times | level2 repeated 2^sh2 times] with only x
+// as the A operand: out = bf16(x W^T + add1[r >> sh1] + add2[r >> sh2]) and the column sums / sums of squares of out
+// as slabs (one per workgroup along x, nparts of them), see RedArgs.  add2 may be NULL.
+extern "C" int pcb_gemm_nt_stats_add_bf16(const void *a, const void *w, long R, int N, int K, void *out, float *sums,
+                                          int nparts, const float *add1, int sh1, const float *add2, int sh2, void *stream)
+{
+    if (!a || !w || !out || !sums || !add1 || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (nparts < 1 || nparts > PCB_MAX_SLABS) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
+    if (sh1 < 2 || sh1 > 30 || (add2 && (sh2 < 2 || sh2 > 30))) return PCB_ERR_UNSUPPORTED;
+    if ((R & ((1L << sh1) - 1)) || (add2 && (R & ((1L << sh2) - 1)))) return PCB_ERR_INVALID_ARG;
+    const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
+    const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
+    const dim3 grid((unsigned)nparts, ny);
+    const RedArgs epi = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, add1, add2, sh1, add2 ? sh2 : sh1};
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
+    hipLaunchKernelGGL((gemm_nt8_kernel<PRO_PLAIN, 2, 0, 4, 4>), grid, dim3(512), 0, st, A, (const u16 *)w, R, N, K,
+                       (u16 *)out, sums, epi);
+    pcb_timer_end(st, timed, nt_bytes(PRO_PLAIN, R, N, K, 0) + 4.0 * (double)(R >> sh1) * N + (add2 ? 4.0 * (double)(R >> sh2) * N : 0.0),
+                  PRO_PLAIN, R, N, K);
+    return pcb_check_launch();
+}
+
+// d add1 [R >> sh1, C], d add2 [R >> sh2, C] (fp32; d2 may be NULL, else sh2 >= sh1) of such a layer from its dz, y and the
+// constants of its BatchNorm backward (the arguments of pcb_dy_rows_bf16).
+extern "C" int pcb_dy_repeat_sums_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *p,
+                                       const float *q, int act, long R, int C, int sh1, float *d1, int sh2, float *d2,
+                                       void *stream)
+{
+    if (!dz || !y || !scale || !shift || !p || !q || !d1 || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(C) || C > 2048) return PCB_ERR_UNSUPPORTED;
+    if (!d2) sh2 = sh1;
+    if (sh1 < 0 || sh2 < sh1 || sh2 > 30) return PCB_ERR_INVALID_ARG;
+    if (R & ((1L << sh2) - 1)) return PCB_ERR_INVALID_ARG;
+    const Operand A = make_operand(dz, y, C, scale, shift, p, q, nullptr, nullptr, 1, act);
+    hipLaunchKernelGGL(dy_repeat_sums_kernel, dim3((unsigned)(R >> sh2)), dim3(256), 0, (hipStream_t)stream, A, R, C, sh1,
+                       d1, sh2, d2);
+    pcb_account(4.0 * R * C + 4.0 * (double)(R >> sh1) * C + (d2 ? 4.0 * (double)(R >> sh2) * C : 0.0));
     return pcb_check_launch();
 }
 

@@ -180,7 +180,12 @@ extern "C" int pcb_timer_read(int category, long *launches, double *milliseconds
 // ---- stack descriptors ------------------------------------------------------------------------
 namespace {
 constexpr int kSlots = 16;  // int64 slots per layer, see include/pcb_hip.h
-enum { S_W = 0, S_BIAS, S_GAMMA, S_BETA, S_RMEAN, S_RVAR, S_C, S_K, S_TRAIN, S_Y, S_DW, S_DGAMMA, S_DBETA, S_DBIAS, S_NBT };
+enum { S_W = 0, S_BIAS, S_GAMMA, S_BETA, S_RMEAN, S_RVAR, S_C, S_K, S_TRAIN, S_Y, S_DW, S_DGAMMA, S_DBETA, S_DBIAS, S_NBT, S_EXT };
+// S_EXT (layer 0 of a plain bf16 stack only): host address of 7 int64 or 0 --
+//   [0] add1, [1] sh1, [2] add2 (or 0), [3] sh2: fp32 rows [R >> sh, C] added to the layer's product before rounding, each
+//       standing for 2^sh consecutive rows (pcb_gemm_nt_stats_add_bf16);  [4] d add1, [5] d add2: their gradients (backward);
+//   [6] row stride of the layer's weight in floats (0 = k): a column slice of a wider weight read in place.
+enum { X_ADD1 = 0, X_SH1, X_ADD2, X_SH2, X_DADD1, X_DADD2, X_LDW };
 
 struct Layer {
     const float *w, *bias, *gamma, *beta;
@@ -189,6 +194,7 @@ struct Layer {
     void *y;
     float *dW, *dgamma, *dbeta, *dbias;
     long long *nbt;  // num_batches_tracked or NULL
+    const long long *ext;  // S_EXT or NULL
     int kp;          // padded input width (= previous layer's C, or the stack's Kp)
     long wp_off;     // element offsets into the weight buffer
     long wt_off;     // -1: no transposed copy
@@ -243,6 +249,8 @@ int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, int
         a.dbeta = ptr<float>(d[S_DBETA]);
         a.dbias = ptr<float>(d[S_DBIAS]);
         a.nbt = ptr<long long>(d[S_NBT]);
+        a.ext = ptr<const long long>(d[S_EXT]);
+        if (a.ext && (l > 0 || gathered)) return PCB_ERR_INVALID_ARG;
         if (gathered && l == 0) {
             // layer 0 = gather_add of per-point products: no weights of its own in this call
             if (!a.y || a.C <= 0 || (a.C % quantum)) return PCB_ERR_INVALID_ARG;
@@ -445,7 +453,7 @@ extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, co
             d[4] = a.k;
             d[5] = a.kp;
             d[6] = (l0 + i == 0) ? perm : 0;
-            d[7] = 0;
+            d[7] = a.ext ? a.ext[X_LDW] : 0;
         }
         PCB_TRY(op.prep_zero(n, pd, cleared ? nullptr : stz, cleared ? 0 : stz_floats, stream));
         cleared = true;
@@ -465,6 +473,15 @@ extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, co
             nparts = want < parts_slabs ? want : parts_slabs;
             PCB_TRY(pcb_gather_add_bf16(ga.u, ga.v, ga.idx, ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.wx, ga.ldw,
                                         a.y, parts, nparts, stream));
+        } else if (a.ext && a.ext[X_ADD1]) {
+            // the coarse levels of a repeated concatenation arrive as addends of the product (see S_EXT); the statistics
+            // epilogue runs in eval mode too (its slabs are then ignored)
+            if (dtype != PCB_DTYPE_BF16) return PCB_ERR_UNSUPPORTED;
+            if (!parts) return PCB_ERR_INVALID_ARG;
+            nparts = slabs_for(0, R, a.C, busy, parts_slabs);
+            PCB_TRY(pcb_gemm_nt_stats_add_bf16(cur, wb + a.wp_off * op.elem, R, a.C, a.kp, a.y, parts, nparts,
+                                               ptr<const float>(a.ext[X_ADD1]), (int)a.ext[X_SH1],
+                                               ptr<const float>(a.ext[X_ADD2]), (int)a.ext[X_SH2], stream));
         } else {
             nparts = stats ? slabs_for(l ? 1 : 0, R, a.C, busy, parts_slabs) : 0;
             PCB_TRY(op.gemm_nt(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0, act,
@@ -615,6 +632,13 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
                 PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx,
                                             ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.u, ga.v, ga.wx, stream));
                 return PCB_OK;
+            }
+            if (a.ext && a.ext[X_DADD1]) {
+                // gradients of the repeated addends: sums of dy over the rows each coarse row stood for
+                if (apro != 2 || dtype != PCB_DTYPE_BF16) return PCB_ERR_UNSUPPORTED;
+                PCB_TRY(pcb_dy_repeat_sums_bf16(dz, a.y, scale, shift, p, q, act, R, a.C, (int)a.ext[X_SH1],
+                                                ptr<float>(a.ext[X_DADD1]), (int)a.ext[X_SH2], ptr<float>(a.ext[X_DADD2]),
+                                                stream));
             }
             // weight gradient, in the parameter's own layout -- on the side stream
             hipEvent_t tn_prev = tn_done;  // gemm_tn(l+1): still reading the buffer gemm_nt(l) will write

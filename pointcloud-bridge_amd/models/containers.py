@@ -123,6 +123,23 @@ class MultiScaleFeatureFusion(nn.Module):
     def forward(self, features_list):
         """[B,C_i,S_i] levels -> [B, N, 3*out] channels-last rows (nearest resampling along the
         point axis, exactly F.interpolate(feat, size=N) of models/model.py:164)."""
+        return self.concat(*self.levels(features_list))
+
+    @staticmethod
+    def concat(outs, reps, B, n):
+        """[B, N, sum C] from levels(): every level repeated to N rows per scene, side by side."""
+        q = rowmlp.mode().q
+        if all(r == 1 for r in reps) or any(o.shape[1] % q for o in outs) or len(outs) > 4:
+            return torch.cat([o.view(B, n // r, 1, -1).expand(B, n // r, r, o.shape[1]).reshape(B, n, -1)
+                              for o, r in zip(outs, reps)], dim=2)
+        # one pass writes every level, broadcast over its repeats, into its column block; backward hands every
+        # level its block of the gradient summed over the repeats (rowmlp.repeat_concat)
+        return rowmlp.repeat_concat(outs, reps).view(B, n, -1)
+
+    def levels(self, features_list):
+        """The levels after their layers, BEFORE upsampling and concatenation: (rows [B*N/r_i, out] per level, how
+        often each row is repeated, B, N).  forward() concatenates them; a consumer that starts with a pointwise conv
+        can take them apart instead (rowmlp.conv_bn_act_levels)."""
         n = features_list[2].shape[2]
         B = features_list[0].shape[0]
 
@@ -162,13 +179,7 @@ class MultiScaleFeatureFusion(nn.Module):
         for i, o in zip(order, res):
             outs[i] = o
         reps = [reps_of[i] for i in range(len(order))]
-        q = rowmlp.mode().q
-        if all(r == 1 for r in reps) or any(o.shape[1] % q for o in outs) or len(outs) > 4:
-            return torch.cat([o.view(B, n // r, 1, -1).expand(B, n // r, r, o.shape[1]).reshape(B, n, -1)
-                              for o, r in zip(outs, reps)], dim=2)
-        # one pass writes every level, broadcast over its repeats, into its column block; backward hands every
-        # level its block of the gradient summed over the repeats (rowmlp.repeat_concat)
-        return rowmlp.repeat_concat(outs, reps).view(B, n, -1)
+        return outs, reps, B, n
 
 
 class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):
@@ -206,10 +217,11 @@ class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, feats, l1)
-        fused = self.fusion([l2, l1, l0])  # [B,N,384] channels-last
-        B, N, _ = fused.shape
+        # fusion's upsample + concatenate [B,N,384] and final_fusion's first conv as one layer over the three levels
+        outs, reps, B, N = self.fusion.levels([l2, l1, l0])
         ff = self.final_fusion
-        x = rowmlp.conv_bn_act(ff[0], ff[1], fused.view(B * N, -1))
+        x = rowmlp.conv_bn_act_levels(ff[0], ff[1], outs, reps,
+                                      concat=lambda: self.fusion.concat(outs, reps, B, N).view(B * N, -1))
         logits = rowmlp.conv_rows(ff[4], ff[3](x), torch.float32)
         return logits.view(B, N, -1).transpose(1, 2)
 
@@ -268,8 +280,10 @@ class EnhancedPointNet2(_SamplingPrefetchMixin, nn.Module):
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, fused_in, l1)
-        fused = self.fusion([l2, l1, l0])
+        # fusion's upsample + concatenate [B,N,384] and final_fusion's first conv as one layer over the three levels
+        outs, reps, B, N = self.fusion.levels([l2, l1, l0])
         ff = self.final_fusion
-        x = rowmlp.conv_bn_act(ff[0], ff[1], fused.view(B * N, -1))
+        x = rowmlp.conv_bn_act_levels(ff[0], ff[1], outs, reps,
+                                      concat=lambda: self.fusion.concat(outs, reps, B, N).view(B * N, -1))
         logits = rowmlp.conv_rows(ff[4], ff[3](x), torch.float32)
         return logits.view(B, N, -1).transpose(1, 2)

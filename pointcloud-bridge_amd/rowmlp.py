@@ -408,7 +408,10 @@ class _FusedStack(torch.autograd.Function):
 
     Flat argument list: x, act, pool, perm, stat_repeat, L, mode, sync group (or False), then per layer
     (weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
-    num_batches_tracked or None -- incremented by the finalize kernel)."""
+    num_batches_tracked or None -- incremented by the finalize kernel); optionally, behind the layers,
+    (add1, add2 or None, sh1, sh2): fp32 rows [R >> sh, C_0] added to layer 0's product, each standing for 2^sh
+    consecutive rows (conv_bn_act_levels; pcb_hip.h desc slot [15]).  Layer 0's weight may then be a column slice of
+    a wider weight."""
 
     NPER = 10
     NHEAD = 8
@@ -418,6 +421,7 @@ class _FusedStack(torch.autograd.Function):
         dev = x.device
         R, Kp = x.shape
         layers = [flat[i * _FusedStack.NPER:(i + 1) * _FusedStack.NPER] for i in range(L)]
+        adds = flat[L * _FusedStack.NPER:] or None
         need_dx = bool(x.requires_grad)
         widths = [t[0].shape[0] for t in layers]
         lib = _lib.load()
@@ -425,14 +429,25 @@ class _FusedStack(torch.autograd.Function):
         ybuf = torch.empty(R * sum(widths), dtype=m.dtype, device=dev)
         stz = torch.empty(10 * sum(widths), dtype=torch.float32, device=dev)
         parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
-        desc = _stack_desc(layers, widths, ybuf, R, m)
+        ext = None
+        if adds is not None:
+            add1, add2, sh1, sh2 = adds
+            for a, sh in ((add1, sh1), (add2, sh2)):
+                if a is not None and not (a.dtype == torch.float32 and a.is_contiguous()
+                                          and a.shape == (R >> sh, widths[0]) and (R >> sh) << sh == R):
+                    raise ValueError("repeated addends: fp32 rows [R >> sh, C] with R a multiple of 2^sh")
+            w0 = layers[0][0]
+            ext = (ctypes.c_longlong * 7)(add1.data_ptr(), sh1, 0 if add2 is None else add2.data_ptr(), sh2, 0, 0,
+                                          0 if w0.is_contiguous() else w0.stride(0))
+        strided = not layers[0][0].is_contiguous()
+        desc = _stack_desc(layers, widths, ybuf, R, m, ext=ext)
         ready = 0
         cache_key = None
         training = any(t[6] for t in layers)
         # pipelined inference: the next batch's FPS may be running beside this pass; training: a hint left
         # over from the backward pass is dropped once its event has completed
         apply_concurrency_hint()
-        if not torch.is_grad_enabled() and not training:
+        if not torch.is_grad_enabled() and not training and not strided:
             cache_key, versions, hit = _eval_lookup(layers, layers[0][0], ("stack", Kp, perm, L, m.code))
             if hit is not None:
                 wbuf, stz = hit
@@ -441,7 +456,11 @@ class _FusedStack(torch.autograd.Function):
             note_parameter_update(weights=False)  # running statistics change under the eval cache's feet
         if not ready:
             nw = lib.pcb_mlp_stack_wbuf_elems(L, desc, Kp, int(need_dx))
-            if cache_key is None:
+            if strided:
+                # a column slice of a wider weight is a fresh view object per call: no registry entry, the call
+                # prepares its operands itself (one small launch)
+                wbuf = torch.empty(nw, dtype=m.dtype, device=dev)
+            elif cache_key is None:
                 # the stack's persistent operand buffer; flag 4: already prepared from these weights (prepare_step)
                 wbuf, ready = _step_operands("stack", [t[0] for t in layers], Kp, perm, need_dx, m, nw, dev)
             else:
@@ -465,6 +484,7 @@ class _FusedStack(torch.autograd.Function):
         ctx.save_for_backward(x, arg, ybuf, stz, wbuf, *[t[0] for t in layers])
         ctx.cfg = (act, pool, perm, L, need_dx, m, group,
                    [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
+        ctx.adds = None if adds is None else (adds[0].shape, None if adds[1] is None else adds[1].shape, adds[2], adds[3])
         return out
 
     @staticmethod
@@ -486,7 +506,8 @@ class _FusedStack(torch.autograd.Function):
             C = widths[l]
             has_bias, has_affine, _ = flags[l]
             base = l * _FusedStack.NPER
-            dw = grads[base + 0] = torch.empty_like(w) if ctx.needs_input_grad[H + base] else None
+            dw = grads[base + 0] = (torch.empty(w.shape, dtype=w.dtype, device=dev)
+                                    if ctx.needs_input_grad[H + base] else None)
             dbias = grads[base + 1] = torch.empty(C, dtype=torch.float32, device=dev) if has_bias else None
             dgamma = grads[base + 2] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
             dbeta = grads[base + 3] = torch.empty(C, dtype=torch.float32, device=dev) if has_affine else None
@@ -495,7 +516,19 @@ class _FusedStack(torch.autograd.Function):
                 ws_elems += lib.pcb_gemm_tn_workspace(R, C, kp)  # one slab region per layer
             kp = C
         layers = [(w, None, None, None, None, None, flags[l][2]) for l, w in enumerate(weights)]
-        desc = _stack_desc(layers, widths, ybuf, R, m, outs)
+        ext, dadds = None, ()
+        if ctx.adds is not None:
+            s1, s2, sh1, sh2 = ctx.adds
+            base = H + L * _FusedStack.NPER
+            d1 = torch.empty(s1, dtype=torch.float32, device=dev) if ctx.needs_input_grad[base] else None
+            d2 = torch.empty(s2, dtype=torch.float32, device=dev) if (s2 is not None and ctx.needs_input_grad[base + 1]) else None
+            if d1 is None and d2 is not None:   # the kernel writes the finer level's sums on its way to the coarser one's
+                d1 = torch.empty(s1, dtype=torch.float32, device=dev)
+            ext = (ctypes.c_longlong * 7)(0, sh1, 0, sh2, 0 if d1 is None else d1.data_ptr(),
+                                          0 if d2 is None else d2.data_ptr(),
+                                          0 if weights[0].is_contiguous() else weights[0].stride(0))
+            dadds = (d1 if ctx.needs_input_grad[base] else None, d2, None, None)
+        desc = _stack_desc(layers, widths, ybuf, R, m, outs, ext=ext)
         want_dx = bool(ctx.needs_input_grad[0]) and need_dx
         dx = torch.empty(R, Kp, dtype=m.dtype, device=dev) if want_dx else None
         # the two gradient ping-pong slots (and, for a wide top layer, its dy written out once): sized by the library
@@ -511,7 +544,7 @@ class _FusedStack(torch.autograd.Function):
                     stz.data_ptr(), parts.data_ptr(), _MAX_PARTS, None if sync is None else sync.ref(), ws.data_ptr(),
                     0 if dzbuf is None else dzbuf.data_ptr(), 0 if dx is None else dx.data_ptr(),
                     check=(None if sync is None else sync.check))
-        return (dx, None, None, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, None, *grads, *dadds)
 
 
 class _PointLinear(torch.autograd.Function):
@@ -583,6 +616,24 @@ class _SplitCols(torch.autograd.Function):
         return torch.cat([ga, gb], dim=1), None
 
 
+class _SplitColsN(torch.autograd.Function):
+    """Column blocks of a 2-D weight as views (widths in order); backward is one concatenation (see _SplitCols)."""
+
+    @staticmethod
+    def forward(ctx, w, widths):
+        ctx.widths, ctx.rows = widths, w.shape[0]
+        outs, o = [], 0
+        for d in widths:
+            outs.append(w[:, o:o + d])
+            o += d
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        return torch.cat([g if g is not None else ref.new_zeros(ctx.rows, d) for g, d in zip(gs, ctx.widths)], dim=1), None
+
+
 def split_cols(w, d):
     """(w[:, :d], w[:, d:]) of a 2-D weight as views, with a single-launch backward (see _SplitCols)."""
     return _SplitCols.apply(w, int(d))
@@ -590,7 +641,8 @@ def split_cols(w, d):
 
 def point_linear(x, w):
     """x [n, K] @ w[C, K]^T -> fp32 [n, C] with bf16 operands (K, C multiples of 8); see _PointLinear."""
-    return _PointLinear.apply(x.to(torch.bfloat16).contiguous(), w.contiguous())
+    # (w may be a column slice of a wider weight: the operand preparation reads it through its row stride)
+    return _PointLinear.apply(x.to(torch.bfloat16).contiguous(), w if w.stride(-1) == 1 else w.contiguous())
 
 
 class _GatheredStack(torch.autograd.Function):
@@ -754,14 +806,17 @@ def gathered_ok(convs, bns):
             and not any(isinstance(b, nn.SyncBatchNorm) for b in bns))
 
 
-def _stack_desc(layers, widths, ybuf, R, m, outs=None):
-    """Host descriptor table of pcb_mlp_stack_forward/backward: 16 int64 per layer (pcb_hip.h)."""
+def _stack_desc(layers, widths, ybuf, R, m, outs=None, ext=None):
+    """Host descriptor table of pcb_mlp_stack_forward/backward: 16 int64 per layer (pcb_hip.h).  ext: layer 0's
+    slot [15] (a ctypes array of 7 int64 the caller keeps alive over the call) or None."""
     vals, yoff = [], 0
     ybase = ybuf.data_ptr()
     esize = ybuf.element_size()
     for l, t in enumerate(layers):
         w, bias, gamma, beta, rm, rv, training = t[:7]
-        if w is not None and not (w.is_contiguous() and w.dtype == torch.float32):
+        sliced = (ext is not None and l == 0 and w is not None and w.dim() == 2 and w.stride(1) == 1
+                  and w.stride(0) >= w.shape[1])
+        if w is not None and not ((w.is_contiguous() or sliced) and w.dtype == torch.float32):
             raise TypeError("fused layers expect contiguous fp32 master weights")
         C = widths[l]
         o = outs[l] if outs is not None else (None, None, None, None)
@@ -772,7 +827,8 @@ def _stack_desc(layers, widths, ybuf, R, m, outs=None):
                  ybase + esize * yoff,
                  0 if o[0] is None else o[0].data_ptr(), 0 if o[1] is None else o[1].data_ptr(),
                  0 if o[2] is None else o[2].data_ptr(), 0 if o[3] is None else o[3].data_ptr(),
-                 t[9].data_ptr() if (len(t) > 9 and t[9] is not None) else 0, 0]
+                 t[9].data_ptr() if (len(t) > 9 and t[9] is not None) else 0,
+                 ctypes.addressof(ext) if (ext is not None and l == 0) else 0]
         yoff += R * C
     return (ctypes.c_longlong * len(vals))(*vals)
 
@@ -1201,6 +1257,43 @@ def repeat_concat(levels, reps):
     MultiScaleFeatureFusion (models/model.py:150-170) without the per-level copies."""
     m = mode()
     return _RepeatConcat.apply(tuple(int(r) for r in reps), m, *[o.to(m.dtype).contiguous() for o in levels])
+
+
+def conv_bn_act_levels(conv, bn, levels, reps, act=ACT_RELU, concat=None):
+    """act(bn(conv(repeat_concat(levels, reps)))) -- MultiScaleFeatureFusion's upsample + concatenate followed by
+    final_fusion's first Conv1d + BatchNorm1d (models/model.py:150-170, :93-99) -- WITHOUT the concatenated rows.
+
+    The conv is linear: its product with [level_a repeated | level_b repeated | full] is
+    full W_f^T + repeat(level_a W_a^T) + repeat(level_b W_b^T).  The coarse levels' shares are formed on their own rows
+    (point_linear, fp32, reps times fewer rows) and enter the full-resolution GEMM as addends of its accumulators
+    (pcb_gemm_nt_stats_add_bf16): the [R, sum C] tensor is neither written nor read, the GEMM and both of its gradient
+    GEMMs shrink to the full level's columns, and the gradient of a coarse level is a sum of dy over its repeats
+    (pcb_dy_repeat_sums_bf16) instead of a [R, sum C] input gradient summed afterwards.  Same arithmetic as the
+    concatenated form up to the order of the fp32 additions (one rounding, after the sum).
+    Falls back to that form (`concat()` builds its rows; default repeat_concat) where the fused one does not apply
+    (fp32 rows, more than two coarse levels, repeats that are not powers of two >= 4)."""
+    m = mode()
+    widths = [int(o.shape[1]) for o in levels]
+    full = [i for i, r in enumerate(reps) if r == 1]
+    coarse = sorted((i for i, r in enumerate(reps) if r != 1), key=lambda i: reps[i])
+    fused = (m is _MODES["bf16"] and len(full) == 1 and 1 <= len(coarse) <= 2 and _stack_fusable([conv], [bn])
+             and all(w % m.q == 0 for w in widths) and sum(widths) == conv.in_channels and levels[0].is_cuda
+             and all(reps[i] >= 4 and (reps[i] & (reps[i] - 1)) == 0 for i in coarse))
+    if fused:
+        x = levels[full[0]]
+        R = x.shape[0]
+        fused = all(levels[i].shape[0] * reps[i] == R for i in coarse)
+    if not fused:
+        return conv_bn_act(conv, bn, repeat_concat(levels, reps) if concat is None else concat(), act)
+    pieces = _SplitColsN.apply(_weight2d(conv), tuple(widths))
+    adds = [point_linear(levels[i], pieces[i]) for i in coarse] + [None] * (2 - len(coarse))
+    shs = [reps[i].bit_length() - 1 for i in coarse]
+    shs += [shs[-1]] * (2 - len(shs))
+    use_sync, group = _sync_group([bn])
+    flat = _layer_args(conv, bn)
+    flat[0] = pieces[full[0]]
+    xr = x if (x.dtype == m.dtype and x.is_contiguous()) else x.to(m.dtype).contiguous()
+    return _FusedStack.apply(xr, act, 0, 0, 1, 1, m, group if use_sync else False, *flat, adds[0], adds[1], shs[0], shs[1])
 
 
 def bn_act_rows(bn, x, act=ACT_NONE):

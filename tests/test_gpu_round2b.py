@@ -326,3 +326,93 @@ def test_conv_rows_with_the_other_branch_added_in_the_epilogue():
         assert torch.equal(got[3], conv.weight.grad) and torch.equal(got[4], conv.bias.grad)
     finally:
         rowmlp.set_precision("fp32")
+
+
+@pytest.mark.parametrize("two", [True, False])
+def test_gemm_with_repeated_addends_and_their_gradient_sums(two):
+    """pcb_gemm_nt_stats_add_bf16: out = bf16(a W^T + add1[r >> sh1] + add2[r >> sh2]) + the statistics slabs of out;
+    pcb_dy_repeat_sums_bf16: sums of dy (as pcb_dy_rows_bf16 writes it) over the rows each coarse row stood for."""
+    from pointcloud_bridge_amd import _lib
+    L = _lib.load()
+    torch.manual_seed(5)
+    R, N, K, sh1, sh2 = 128 * 37, 136, 72, 2, 5     # a ragged last column tile, a partly filled last grid pass
+    a = torch.randn(R, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.2).to(torch.bfloat16)
+    add1 = torch.randn(R >> sh1, N, device="cuda")
+    add2 = torch.randn(R >> sh2, N, device="cuda") if two else None
+    out = torch.empty(R, N, dtype=torch.bfloat16, device="cuda")
+    nparts = 19
+    sums = torch.full((nparts, 2, N), float("nan"), device="cuda")
+    assert L.pcb_gemm_nt_stats_add_bf16(a.data_ptr(), w.data_ptr(), R, N, K, out.data_ptr(), sums.data_ptr(), nparts,
+                                        add1.data_ptr(), sh1, 0 if add2 is None else add2.data_ptr(), sh2, _stream()) == 0
+    ref = a.float() @ w.float().t() + add1.repeat_interleave(1 << sh1, dim=0)
+    if two:
+        ref = ref + add2.repeat_interleave(1 << sh2, dim=0)
+    assert (out.float() - ref).abs().max() <= 2e-2 * ref.abs().max()     # one bf16 rounding of an fp32 sum
+    tot = sums.double().sum(0)
+    assert torch.allclose(tot[0], out.double().sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(tot[1], (out.double() ** 2).sum(0), rtol=1e-5, atol=1e-3)
+    # shifts below 2 are refused (the epilogue takes one coarse row per run of 4 output rows)
+    assert L.pcb_gemm_nt_stats_add_bf16(a.data_ptr(), w.data_ptr(), R, N, K, out.data_ptr(), sums.data_ptr(), nparts,
+                                        add1.data_ptr(), 1, 0, 1, _stream()) < 0
+
+    C = N
+    dz = torch.randn(R, C, device="cuda").to(torch.bfloat16)
+    y = torch.randn(R, C, device="cuda").to(torch.bfloat16)
+    scale, shift, p, q = (torch.randn(C, device="cuda") * s for s in (1.0, 0.3, 0.05, 0.05))
+    dy = torch.empty(R, C, dtype=torch.bfloat16, device="cuda")
+    assert L.pcb_dy_rows_bf16(dz.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), p.data_ptr(), q.data_ptr(),
+                              1, R, C, dy.data_ptr(), _stream()) == 0
+    d1 = torch.full((R >> sh1, C), float("nan"), device="cuda")
+    d2 = torch.full((R >> sh2, C), float("nan"), device="cuda") if two else None
+    assert L.pcb_dy_repeat_sums_bf16(dz.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), p.data_ptr(),
+                                     q.data_ptr(), 1, R, C, sh1, d1.data_ptr(), sh2, 0 if d2 is None else d2.data_ptr(),
+                                     _stream()) == 0
+    assert torch.allclose(d1, dy.float().view(R >> sh1, 1 << sh1, C).sum(1), rtol=1e-5, atol=1e-5)
+    if two:
+        assert torch.allclose(d2, dy.float().view(R >> sh2, 1 << sh2, C).sum(1), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_conv_over_repeated_levels_equals_the_concatenated_form(train):
+    """rowmlp.conv_bn_act_levels (MultiScaleFeatureFusion's upsample + concat followed by final_fusion's first
+    conv + BatchNorm, models/model.py:150-170, :93-99, without the concatenated rows) against the same layer on
+    repeat_concat's rows: output, running statistics and every gradient."""
+    from pointcloud_bridge_amd import rowmlp
+    rowmlp.set_precision("bf16")
+    try:
+        torch.manual_seed(21)
+        R, reps, widths = 4096, [32, 16, 1], [128, 64, 128]
+        conv = torch.nn.Conv1d(sum(widths), 128, 1).cuda()
+        bn = torch.nn.BatchNorm1d(128).cuda()
+        bn.train(train)
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.1)
+            bn.running_var.uniform_(0.5, 1.5)
+        ref_bn = torch.nn.BatchNorm1d(128).cuda()
+        ref_bn.load_state_dict(bn.state_dict())
+        ref_bn.train(train)
+        levels = [torch.randn(R // r, c, device="cuda").to(torch.bfloat16).requires_grad_(True) for r, c in zip(reps, widths)]
+        g = torch.randn(R, 128, device="cuda").to(torch.bfloat16)
+
+        out = rowmlp.conv_bn_act_levels(conv, bn, levels, reps)
+        out.backward(g)
+        got = [out.detach().float()] + [t.grad.float() for t in levels] + [conv.weight.grad.clone(), bn.weight.grad.clone(),
+                                                                            bn.bias.grad.clone()]
+        for t in levels + [conv.weight, conv.bias, bn.weight, bn.bias]:
+            t.grad = None
+        ref = rowmlp.conv_bn_act(conv, ref_bn, rowmlp.repeat_concat(levels, reps))
+        ref.backward(g)
+        want = [ref.detach().float()] + [t.grad.float() for t in levels] + [conv.weight.grad, ref_bn.weight.grad, ref_bn.bias.grad]
+        names = ["out", "d level0", "d level1", "d level2", "d weight", "d gamma", "d beta"]
+        for n, a, b in zip(names, got, want):
+            err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+            assert err < 2e-2, (n, err)     # bf16 operands / results on both sides, fp32 sums in a different order
+        assert torch.allclose(bn.running_mean, ref_bn.running_mean, rtol=1e-3, atol=1e-3)
+        assert torch.allclose(bn.running_var, ref_bn.running_var, rtol=1e-3, atol=1e-3)
+        # fp32 rows: the concatenated form runs (no fused variant), same call
+        rowmlp.set_precision("fp32")
+        out32 = rowmlp.conv_bn_act_levels(conv, bn, [t.detach().float() for t in levels], reps)
+        assert out32.dtype == torch.float32 and out32.shape == (R, 128)
+    finally:
+        rowmlp.set_precision("fp32")
