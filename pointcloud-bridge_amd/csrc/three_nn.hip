@@ -287,8 +287,10 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t *__restrict
     }
 }
 
-// one wave per target (b, s); a half-wave (32 lanes x E channels) covers up to 32*E channels, wider
-// rows loop over blocks of that size.  g is a [B*N, ld] buffer, columns col0 .. col0+C.
+// one wave per target (b, s).  An entry's row is read by `lpe` lanes (E channels each; lpe = the row's chunks rounded up
+// to a power of two, at most 32: wider rows loop over blocks of 32*E channels), so the wave's 64 / lpe lane groups walk
+// 64 / lpe entries side by side -- 2 for the wide decoder rows, 8 for a 64-column row.  g is a [B*N, ld] buffer,
+// columns col0 .. col0+C.
 template <typename T>
 __global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const T *__restrict__ g, int ld, int col0,
                                                                    const float *__restrict__ w,
@@ -299,28 +301,30 @@ __global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const T *__res
 {
     constexpr int E = RowVec<T>::E;
     const int lane = threadIdx.x & 63;
-    const int half = lane >> 5, hl = lane & 31;
+    int lpe = 1;
+    while (lpe < 32 && lpe * E < C) lpe <<= 1;
+    const int groups = 64 / lpe, grp = lane / lpe, gl = lane % lpe;
     const long seg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seg >= segments) return;  // wave-uniform
     const long b = seg / S;
     const long beg = offsets[seg], end = offsets[seg + 1];
-    for (int c0 = 0; c0 < C; c0 += 32 * E) {
-        const int c = c0 + hl * E;
+    for (int c0 = 0; c0 < C; c0 += lpe * E) {
+        const int c = c0 + gl * E;
         float acc[E];
 #pragma unroll
         for (int i = 0; i < E; ++i) acc[i] = 0.0f;
-        // four entries per half-wave and step: their index, weight and row loads are issued together (one entry per
+        // four entries per lane group and step: their index, weight and row loads are issued together (one entry per
         // step made every row load wait for its own index load: a chain of two memory latencies per entry), the
         // products are added in entry order as before
         const int cs = c < C ? c : 0;
-        for (long e0 = beg + half; e0 < end; e0 += 8) {
+        for (long e0 = beg + grp; e0 < end; e0 += 4 * groups) {
             int ent[4];
             long row[4];
             float wt[4];
             uint4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long e = e0 + 2 * u < end ? e0 + 2 * u : beg;     // (beg: a valid entry, masked below)
+                const long e = e0 + groups * u < end ? e0 + groups * u : beg;     // (beg: a valid entry, masked below)
                 ent[u] = entries[e];
             }
 #pragma unroll
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const T *__res
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (e0 + 2 * u >= end) break;
+                if (e0 + groups * u >= end) break;
                 if (c < C) {
                     float f[E];
                     RowVec<T>::unpack(v[u], f);
@@ -341,9 +345,10 @@ __global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const T *__res
                 }
             }
         }
+        for (int o = lpe; o < 64; o <<= 1)
 #pragma unroll
-        for (int i = 0; i < E; ++i) acc[i] += __shfl_xor(acc[i], 32);
-        if (half == 0 && c < C)
+            for (int i = 0; i < E; ++i) acc[i] += __shfl_xor(acc[i], o);
+        if (grp == 0 && c < C)
             *reinterpret_cast<uint4 *>(gfeat + seg * (long)C + c) = RowVec<T>::pack(acc);
     }
 }
