@@ -83,6 +83,8 @@ void pcb_timer_begin(hipStream_t st, hipEvent_t *stop) { pcb_timer_begin_cat(st,
 
 void pcb_timer_end(hipStream_t st, hipEvent_t stop, double bytes, int pro, long R, int N, int K)
 {
+    static const bool trace = getenv("PCB_NT_TRACE") != nullptr;  // launch list for tools/nt_bench.py
+    if (trace && R > 0) fprintf(stderr, "[pcb_nt] %d %ld %d %d\n", pro, R, N, K);
     pcb_account(bytes);
     if (!stop) return;
     (void)hipEventRecord(stop, st);

@@ -21,6 +21,7 @@ statistics are kept exactly as nn.BatchNorm does, so state_dicts stay interchang
 nn.SyncBatchNorm layers all-reduce their statistics over the process group (parallel.py).
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -1278,7 +1279,8 @@ def conv_bn_act_levels(conv, bn, levels, reps, act=ACT_RELU, concat=None):
     coarse = sorted((i for i, r in enumerate(reps) if r != 1), key=lambda i: reps[i])
     fused = (m is _MODES["bf16"] and len(full) == 1 and 1 <= len(coarse) <= 2 and _stack_fusable([conv], [bn])
              and all(w % m.q == 0 for w in widths) and sum(widths) == conv.in_channels and levels[0].is_cuda
-             and all(reps[i] >= 4 and (reps[i] & (reps[i] - 1)) == 0 for i in coarse))
+             and all(reps[i] >= 4 and (reps[i] & (reps[i] - 1)) == 0 for i in coarse)
+             and os.environ.get("PCB_LEVELS_FUSED", "1") != "0")    # (A/B knob: tools/ab_env.sh)
     if fused:
         x = levels[full[0]]
         R = x.shape[0]

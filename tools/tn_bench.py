@@ -17,8 +17,15 @@ from pointcloud_bridge_amd import _lib  # noqa: E402
 
 def shapes(path):
     rows = [tuple(int(v) for v in l.split()[1:]) for l in open(path) if l.startswith("[pcb_tn]")]
-    per_step = 41 if len(rows) % 41 == 0 else len(rows)
-    return rows[-per_step:]
+    return last_period(rows)
+
+
+def last_period(rows):
+    """The last step of a trace that holds several identical steps (the shortest period the tail repeats with)."""
+    for p in range(8, len(rows) // 2 + 1):
+        if rows[-p:] == rows[-2 * p:-p]:
+            return rows[-p:]
+    return rows
 
 
 def main():
