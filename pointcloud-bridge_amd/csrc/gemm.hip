@@ -952,8 +952,12 @@ __device__ __forceinline__ unsigned xcd_logical(unsigned id, unsigned total)
 // ASUM (plain A operand only): the column sums of A over the split's rows are stored behind the split's [M,N]
 // slab -- for a conv with a bias that is its bias gradient (sum of dy over the rows), which otherwise costs a
 // pass of its own over dy.  `stride` = floats from one split's slab to the next (M*N, or M*N + M with ASUM).
-template <int APRO, int BPRO, int ASUM = 0>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand B_arg, long R, int M, int N,
+// TEAMS = 2: two four-wave teams in one workgroup, each with its own stage buffers and its own half of the split's
+// rows; at the end team 1 hands its accumulators to team 0 through LDS and ONE slab is written for both.  The slabs
+// (splits x M x N floats, written here and read again by the slab sum) were a third of the traffic of the step's
+// weight gradients at one slab per four waves; the waves per CU, their loads and MFMAs are the same as before.
+template <int APRO, int BPRO, int ASUM = 0, int TEAMS = 1>
+__global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kernel(Operand A_arg, Operand B_arg, long R, int M, int N,
                                                        long rows_per_split, float *__restrict__ part, long stride,
                                                        int tiles_m, int tiles_n)
 {
@@ -961,10 +965,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     const Operand A = local_copy(A_arg);
     const Operand B = local_copy(B_arg);
     const float a_slope = act_slope(A.act), b_slope = act_slope(B.act);
-    __shared__ __attribute__((aligned(16))) u16 As[2 * TN_RS * TN_LD];   // two stage buffers each
-    __shared__ __attribute__((aligned(16))) u16 Bs[2 * TN_RS * TN_LD];
+    // per team: two stage buffers per operand
+    __shared__ __attribute__((aligned(16))) u16 smem[TEAMS * 4 * TN_RS * TN_LD];
+    const int team = TEAMS == 1 ? 0 : (int)(threadIdx.x >> 8);
+    u16 *const As = smem + team * (4 * TN_RS * TN_LD);
+    u16 *const Bs = As + 2 * TN_RS * TN_LD;
 
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 outputs each
@@ -976,8 +983,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
     const int split = logical / (tiles_n * tiles_m);
     const int m0 = tile_m * TN_BM;
     const int n0 = tile_n * TN_BN;
-    const long r_begin = (long)split * rows_per_split;
-    const long r_end = r_begin + rows_per_split < R ? r_begin + rows_per_split : R;
+    // the workgroup's rows, divided among its teams in whole stages; every team runs the same number of stages
+    // (the barriers are the workgroup's): rows past a team's range load as zeros
+    const long wg_begin = (long)split * rows_per_split;
+    const long wg_end = wg_begin + rows_per_split < R ? wg_begin + rows_per_split : R;
+    const long per_team = ((wg_end - wg_begin + TEAMS - 1) / TEAMS + TN_RS - 1) / TN_RS * TN_RS;
+    const long r_begin = wg_begin + team * per_team < wg_end ? wg_begin + team * per_team : wg_end;
+    const long r_end = r_begin + per_team < wg_end ? r_begin + per_team : wg_end;
+    const long r_stop = r_begin + (wg_begin < wg_end ? per_team : 0);   // uniform stage count
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -1032,14 +1045,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
             }
         }
     };
-    if (r_begin < r_end) {
+    if (r_begin < r_stop) {
         fetch(r_begin);
         park(0);
-        if (r_begin + TN_RS < r_end) fetch(r_begin + TN_RS);
+        if (r_begin + TN_RS < r_stop) fetch(r_begin + TN_RS);
     }
     __syncthreads();
     int cur = 0;
-    for (long r0 = r_begin; r0 < r_end; r0 += TN_RS, cur ^= 1) {
+    for (long r0 = r_begin; r0 < r_stop; r0 += TN_RS, cur ^= 1) {
         const u16 *const Ab = As + cur * (TN_RS * TN_LD);
         const u16 *const Bb = Bs + cur * (TN_RS * TN_LD);
 #pragma unroll
@@ -1063,13 +1076,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        if (r0 + TN_RS < r_end) {
+        if (r0 + TN_RS < r_stop) {
             park(cur ^ 1);
-            if (r0 + 2 * TN_RS < r_end) fetch(r0 + 2 * TN_RS);
+            if (r0 + 2 * TN_RS < r_stop) fetch(r0 + 2 * TN_RS);
         }
         __syncthreads();
     }
 
+    if (TEAMS == 2) {
+        // team 1's accumulators (and column sums) join team 0's: thread t of both teams holds the same outputs, so the
+        // exchange is [value][t] (conflict-free); 64 + 8 values x 256 floats = 72 KB of the 80 KB of stage buffers
+        float *const xch = reinterpret_cast<float *>(smem);
+        if (team == 1) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) xch[((a * 2 + b) * 16 + i) * 256 + t] = acc[a][b][i];
+            if (ASUM)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xch[(64 + e) * 256 + t] = asum[e];
+        }
+        __syncthreads();
+        if (team == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[a][b][i] += xch[((a * 2 + b) * 16 + i) * 256 + t];
+            if (ASUM)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asum[e] += xch[(64 + e) * 256 + t];
+        }
+    }
+    if (team == 0) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1083,14 +1125,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Operand A_arg, Operand 
                 if (m < M && n < N) part[(long)split * stride + (long)m * N + n] = acc[a][b][i];
             }
         }
+    }
     if (ASUM && tile_n == 0) {
         // the 16 threads that share a column chunk (t & 15) meet in LDS (the stage buffers are idle now), fixed order
-        float *const red = reinterpret_cast<float *>(As);   // [16][128]
+        float *const red = reinterpret_cast<float *>(smem);   // [16][128] (team 0's values)
         __syncthreads();
+        if (team == 0)
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[rrow * 128 + chunk * 8 + e] = asum[e];
         __syncthreads();
-        if (t < 128 && m0 + t < M) {
+        if (team == 0 && t < 128 && m0 + t < M) {
             float a = 0.0f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) a += red[i * 128 + t];
@@ -1207,16 +1251,31 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
     static const bool trace = getenv("PCB_TN_TRACE") != nullptr;  // launch list for tools/tn_bench.py
     if (trace) fprintf(stderr, "[pcb_tn] %d %d %ld %d %d %d\n", APRO, bpro, R, M, N, colsum ? 1 : 0);
     // fewer splits while another kernel holds CUs (never more than pcb_gemm_tn_workspace assumed)
-    const long splits = pcb_tn_splits(R, M, N, &rps, 512 - 2 * pcb_busy_cus());
+    // two four-wave teams per workgroup (one slab for both) unless PCB_TN_TEAMS=1 asks for the one-team form: half as
+    // many workgroups of twice the size, the same waves per CU (never more splits than pcb_gemm_tn_workspace assumed)
+    static const bool one_team_env = getenv("PCB_TN_TEAMS") && atoi(getenv("PCB_TN_TEAMS")) == 1;
+    const long target = 512 - 2 * pcb_busy_cus();
     const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
+    // a two-team workgroup (80 KB of LDS) has a CU to itself: the grid must not exceed the CUs it may use, or its last
+    // few workgroups run as a second round (258 workgroups for 6 tiles x 43 splits took 1.45x the time of 252); matrices
+    // of more than 64 tiles would leave a quarter of the chip idle that way and keep the one-team form
+    const bool one_team = one_team_env || tm * tn > 64;
+    const long splits = pcb_tn_splits(R, M, N, &rps, one_team ? target : ((target / 2) / (tm * tn) > 0 ? (target / 2) / (tm * tn) : 1) * (tm * tn));
     const dim3 grid((unsigned)(tm * tn * splits));
     const long stride = (long)M * N + (colsum ? M : 0);
-    if (colsum && APRO == PRO_PLAIN && bpro == PRO_PLAIN)
-        hipLaunchKernelGGL((gemm_tn_kernel<PRO_PLAIN, PRO_PLAIN, 1>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
+    if (one_team) {
+        if (colsum && APRO == PRO_PLAIN && bpro == PRO_PLAIN)
+            hipLaunchKernelGGL((gemm_tn_kernel<PRO_PLAIN, PRO_PLAIN, 1>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
+        else if (bpro == PRO_PLAIN)
+            hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
+    } else if (colsum && APRO == PRO_PLAIN && bpro == PRO_PLAIN)
+        hipLaunchKernelGGL((gemm_tn_kernel<PRO_PLAIN, PRO_PLAIN, 1, 2>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
     else if (bpro == PRO_PLAIN)
-        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
+        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN, 0, 2>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
+        hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT, 0, 2>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
     (void)pcb_reduce_slabs_vec(part, (int)splits, stride, (long)M * N, dW, N, out_cols, out_perm, 8, colsum, M, st);
 }
 
