@@ -955,10 +955,10 @@ __device__ __forceinline__ unsigned xcd_logical(unsigned id, unsigned total)
 // rows; at the end team 1 hands its accumulators to team 0 through LDS and ONE slab is written for both.  The slabs
 // (splits x M x N floats, written here and read again by the slab sum) were a third of the traffic of the step's
 // weight gradients at one slab per four waves; the waves per CU, their loads and MFMAs are the same as before.
-// TW = 64: both matrices at most 64 columns wide (the first layers of the set-abstraction stacks): a 64 x 64 output tile,
-// 32 x 32 per wave, and 64 rows per stage instead of 32 -- a 128-wide tile would stage and multiply three quarters of
-// padding for them.
-template <int APRO, int BPRO, int ASUM = 0, int TEAMS = 1, int TW = 128>
+// TWA / TWB = 64: an operand of at most 64 columns (the first layers of the set-abstraction stacks, the narrow attention
+// layers) gets a 64-wide tile -- 32 columns per wave -- and the stage grows to 64 rows: a 128-wide tile would stage and
+// multiply half (both narrow: three quarters) of padding for it.
+template <int APRO, int BPRO, int ASUM = 0, int TEAMS = 1, int TWA = 128, int TWB = TWA>
 __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kernel(Operand A_arg, Operand B_arg, long R, int M, int N,
                                                        long rows_per_split, float *__restrict__ part, long stride,
                                                        int tiles_m, int tiles_n)
@@ -967,30 +967,32 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kerne
     const Operand A = local_copy(A_arg);
     const Operand B = local_copy(B_arg);
     const float a_slope = act_slope(A.act), b_slope = act_slope(B.act);
-    constexpr int RS = TW == 64 ? 64 : TN_RS;      // rows of the reduction per stage
-    constexpr int LD = TW + 32;                    // LDS row stride in bf16 (320 / 192 B: conflict-free tr reads)
-    constexpr int CH = TW / 8, RPP = 256 / CH;     // 16-byte chunks per row; rows one pass of the team's 256 threads covers
-    constexpr int NCH = RS / RPP;                  // chunks per thread, operand and stage
-    constexpr int XN = TW / 64;                    // 32-wide MFMA tiles per wave and direction
-    static_assert(TW == 128 ? LD == TN_LD : true, "the 128-wide form keeps its layout");
+    constexpr int RS = (TWA == 64 || TWB == 64) ? 64 : TN_RS;   // rows of the reduction per stage
+    constexpr int LDA = TWA + 32, LDB = TWB + 32;  // LDS row strides in bf16 (320 / 192 B: conflict-free tr reads)
+    constexpr int CHA = TWA / 8, RPPA = 256 / CHA; // 16-byte chunks per row; rows one pass of the team's 256 threads covers
+    constexpr int CHB = TWB / 8, RPPB = 256 / CHB;
+    constexpr int NCHA = RS / RPPA, NCHB = RS / RPPB;  // chunks per thread and stage
+    constexpr int XNA = TWA / 64, XNB = TWB / 64;  // 32-wide MFMA tiles per wave
+    static_assert(TWA == 128 ? LDA == TN_LD : true, "the 128-wide form keeps its layout");
+    static_assert(TEAMS == 1 || (XNA * XNB * 16 + 8) * 256 * 4 <= TEAMS * 2 * RS * (LDA + LDB) * 2, "the exchange must fit the stage buffers");
     // per team: two stage buffers per operand
-    __shared__ __attribute__((aligned(16))) u16 smem[TEAMS * 4 * RS * LD];
+    __shared__ __attribute__((aligned(16))) u16 smem[TEAMS * 2 * RS * (LDA + LDB)];
     const int team = TEAMS == 1 ? 0 : (int)(threadIdx.x >> 8);
-    u16 *const As = smem + team * (4 * RS * LD);
-    u16 *const Bs = As + 2 * RS * LD;
+    u16 *const As = smem + team * (2 * RS * (LDA + LDB));
+    u16 *const Bs = As + 2 * RS * LDA;
 
     const int t = threadIdx.x & 255;
     const int lane = t & 63;
     const int wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 (TW = 64: 32 x 32) outputs each
+    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, (TWA / 2) x (TWB / 2) outputs each
     // 1-D grid; the N tiles (then M tiles) of one row split are neighbours on one XCD, so the
     // operand rows they share are fetched from HBM once and found in that XCD's L2 afterwards
     const unsigned logical = xcd_logical(blockIdx.x, gridDim.x);
     const int tile_n = logical % tiles_n;
     const int tile_m = (logical / tiles_n) % tiles_m;
     const int split = logical / (tiles_n * tiles_m);
-    const int m0 = tile_m * TW;
-    const int n0 = tile_n * TW;
+    const int m0 = tile_m * TWA;
+    const int n0 = tile_n * TWB;
     // the workgroup's rows, divided among its teams in whole stages; every team runs the same number of stages
     // (the barriers are the workgroup's): rows past a team's range load as zeros
     const long wg_begin = (long)split * rows_per_split;
@@ -1000,30 +1002,35 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kerne
     const long r_end = r_begin + per_team < wg_end ? r_begin + per_team : wg_end;
     const long r_stop = r_begin + (wg_begin < wg_end ? per_team : 0);   // uniform stage count
 
-    f32x16 acc[XN][XN];
+    f32x16 acc[XNA][XNB];
 #pragma unroll
-    for (int a = 0; a < XN; ++a)
+    for (int a = 0; a < XNA; ++a)
 #pragma unroll
-        for (int b = 0; b < XN; ++b)
+        for (int b = 0; b < XNB; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-    // staging: RS rows x 16 chunks of 8 columns per operand -> NCH chunks per thread and operand.
+    // staging: RS rows x TW / 8 chunks of 8 columns per operand -> NCHA / NCHB chunks per thread.
     // A thread's column chunk never changes, so its per-column constants stay in registers.
-    const int chunk = t % CH;
-    const int rrow = t / CH;  // 0..RPP-1
+    const int chunk = t % CHA, chunkb = t % CHB;
+    const int rrow = t / CHA, rrowb = t / CHB;  // 0..RPP-1
     Consts<APRO> ka;
     Consts<BPRO> kb;
     ka.load(A, m0 + chunk * 8, M);
-    kb.load(B, n0 + chunk * 8, N);
-    Raw<APRO> ra[NCH];
-    Raw<BPRO> rb[NCH];
+    kb.load(B, n0 + chunkb * 8, N);
+    Raw<APRO> ra[NCHA];
+    Raw<BPRO> rb[NCHB];
     auto fetch = [&](long r0) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const long r = r0 + rrow + RPP * i;
-            ra[i].load(A, r < r_end ? r : R, m0 + chunk * 8, R, M);
-            rb[i].load(B, r < r_end ? r : R, n0 + chunk * 8, R, N);
+        for (int i = 0; i < (NCHA > NCHB ? NCHA : NCHB); ++i) {   // (interleaved: the order the 128-wide form was tuned with)
+            if (i < NCHA) {
+                const long r = r0 + rrow + RPPA * i;
+                ra[i].load(A, r < r_end ? r : R, m0 + chunk * 8, R, M);
+            }
+            if (i < NCHB) {
+                const long r = r0 + rrowb + RPPB * i;
+                rb[i].load(B, r < r_end ? r : R, n0 + chunkb * 8, R, N);
+            }
         }
     };
     // transposed-read addresses: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a
@@ -1038,19 +1045,21 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kerne
     // publishes buffer (s+1) & 1 and retires the reads of buffer s & 1.
     float asum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     auto park = [&](int buf) {
-        u16 *const Ab = As + buf * (RS * LD);
-        u16 *const Bb = Bs + buf * (RS * LD);
+        u16 *const Ab = As + buf * (RS * LDA);
+        u16 *const Bb = Bs + buf * (RS * LDB);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const uint4 av = ra[i].finish(ka, a_slope);
-            *reinterpret_cast<uint4 *>(&Ab[(rrow + RPP * i) * LD + chunk * 8]) = av;
-            *reinterpret_cast<uint4 *>(&Bb[(rrow + RPP * i) * LD + chunk * 8]) = rb[i].finish(kb, b_slope);
-            if (ASUM) {
-                float f[8];
-                unpack8(av, f);  // rows outside the split are zero already
+        for (int i = 0; i < (NCHA > NCHB ? NCHA : NCHB); ++i) {
+            if (i < NCHA) {
+                const uint4 av = ra[i].finish(ka, a_slope);
+                *reinterpret_cast<uint4 *>(&Ab[(rrow + RPPA * i) * LDA + chunk * 8]) = av;
+                if (ASUM) {
+                    float f[8];
+                    unpack8(av, f);  // rows outside the split are zero already
 #pragma unroll
-                for (int e = 0; e < 8; ++e) asum[e] += f[e];
+                    for (int e = 0; e < 8; ++e) asum[e] += f[e];
+                }
             }
+            if (i < NCHB) *reinterpret_cast<uint4 *>(&Bb[(rrowb + RPPB * i) * LDB + chunkb * 8]) = rb[i].finish(kb, b_slope);
         }
     };
     if (r_begin < r_stop) {
@@ -1061,27 +1070,31 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kerne
     __syncthreads();
     int cur = 0;
     for (long r0 = r_begin; r0 < r_stop; r0 += RS, cur ^= 1) {
-        const u16 *const Ab = As + cur * (RS * LD);
-        const u16 *const Bb = Bs + cur * (RS * LD);
+        const u16 *const Ab = As + cur * (RS * LDA);
+        const u16 *const Bb = Bs + cur * (RS * LDB);
 #pragma unroll
         for (int ks = 0; ks < RS / 16; ++ks) {
-            bf16x8 af[XN], bf[XN];
+            bf16x8 af[XNA], bf[XNB];
+            typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
 #pragma unroll
-            for (int x = 0; x < XN; ++x) {
-                const u16 *pa = &Ab[(ks * 16 + tr_row) * LD + wm * (TW / 2) + x * 32 + tr_col];
-                const u16 *pb = &Bb[(ks * 16 + tr_row) * LD + wn * (TW / 2) + x * 32 + tr_col];
-                typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
-                const s16x4 a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pa);
-                const s16x4 a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pa + 4 * LD));
-                const s16x4 b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pb);
-                const s16x4 b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pb + 4 * LD));
-                af[x] = __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                bf[x] = __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int x = 0; x < (XNA > XNB ? XNA : XNB); ++x) {
+                if (x < XNA) {
+                    const u16 *pa = &Ab[(ks * 16 + tr_row) * LDA + wm * (TWA / 2) + x * 32 + tr_col];
+                    const s16x4 a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pa);
+                    const s16x4 a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pa + 4 * LDA));
+                    af[x] = __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                if (x < XNB) {
+                    const u16 *pb = &Bb[(ks * 16 + tr_row) * LDB + wn * (TWB / 2) + x * 32 + tr_col];
+                    const s16x4 b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pb);
+                    const s16x4 b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pb + 4 * LDB));
+                    bf[x] = __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             }
 #pragma unroll
-            for (int a = 0; a < XN; ++a)
+            for (int a = 0; a < XNA; ++a)
 #pragma unroll
-                for (int b = 0; b < XN; ++b)
+                for (int b = 0; b < XNB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
         if (r0 + RS < r_stop) {
@@ -1097,37 +1110,37 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kerne
         float *const xch = reinterpret_cast<float *>(smem);
         if (team == 1) {
 #pragma unroll
-            for (int a = 0; a < XN; ++a)
+            for (int a = 0; a < XNA; ++a)
 #pragma unroll
-                for (int b = 0; b < XN; ++b)
+                for (int b = 0; b < XNB; ++b)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) xch[((a * XN + b) * 16 + i) * 256 + t] = acc[a][b][i];
+                    for (int i = 0; i < 16; ++i) xch[((a * XNB + b) * 16 + i) * 256 + t] = acc[a][b][i];
             if (ASUM)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xch[(XN * XN * 16 + e) * 256 + t] = asum[e];
+                for (int e = 0; e < 8; ++e) xch[(XNA * XNB * 16 + e) * 256 + t] = asum[e];
         }
         __syncthreads();
         if (team == 0) {
 #pragma unroll
-            for (int a = 0; a < XN; ++a)
+            for (int a = 0; a < XNA; ++a)
 #pragma unroll
-                for (int b = 0; b < XN; ++b)
+                for (int b = 0; b < XNB; ++b)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[a][b][i] += xch[((a * XN + b) * 16 + i) * 256 + t];
+                    for (int i = 0; i < 16; ++i) acc[a][b][i] += xch[((a * XNB + b) * 16 + i) * 256 + t];
             if (ASUM)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) asum[e] += xch[(XN * XN * 16 + e) * 256 + t];
+                for (int e = 0; e < 8; ++e) asum[e] += xch[(XNA * XNB * 16 + e) * 256 + t];
         }
     }
     if (team == 0) {
 #pragma unroll
-    for (int a = 0; a < XN; ++a)
+    for (int a = 0; a < XNA; ++a)
 #pragma unroll
-        for (int b = 0; b < XN; ++b) {
-            const int n = n0 + wn * (TW / 2) + b * 32 + (lane & 31);
+        for (int b = 0; b < XNB; ++b) {
+            const int n = n0 + wn * (TWB / 2) + b * 32 + (lane & 31);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int m = m0 + wm * (TW / 2) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * (TWA / 2) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 // one plain store per element into this split's slab (summed by reduce_slabs_kernel):
                 // thousands of workgroups adding into one small dW would serialise on its few lines
                 if (m < M && n < N) part[(long)split * stride + (long)m * N + n] = acc[a][b][i];
@@ -1136,16 +1149,16 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kerne
     }
     if (ASUM && tile_n == 0) {
         // the 16 threads that share a column chunk (t & 15) meet in LDS (the stage buffers are idle now), fixed order
-        float *const red = reinterpret_cast<float *>(smem);   // [RPP][TW] (team 0's values)
+        float *const red = reinterpret_cast<float *>(smem);   // [RPPA][TWA] (team 0's values)
         __syncthreads();
         if (team == 0)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[rrow * TW + chunk * 8 + e] = asum[e];
+        for (int e = 0; e < 8; ++e) red[rrow * TWA + chunk * 8 + e] = asum[e];
         __syncthreads();
-        if (team == 0 && t < TW && m0 + t < M) {
+        if (team == 0 && t < TWA && m0 + t < M) {
             float a = 0.0f;
 #pragma unroll
-            for (int i = 0; i < RPP; ++i) a += red[i * TW + t];
+            for (int i = 0; i < RPPA; ++i) a += red[i * TWA + t];
             part[(long)split * stride + (long)M * N + m0 + t] = a;
         }
     }
@@ -1263,13 +1276,14 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
     // many workgroups of twice the size, the same waves per CU (never more splits than pcb_gemm_tn_workspace assumed)
     static const bool one_team_env = getenv("PCB_TN_TEAMS") && atoi(getenv("PCB_TN_TEAMS")) == 1;
     const long target = 512 - 2 * pcb_busy_cus();
-    const int tm = (M + TN_BM - 1) / TN_BM, tn = (N + TN_BN - 1) / TN_BN;
+    static const bool no_narrow = getenv("PCB_TN_NARROW") && atoi(getenv("PCB_TN_NARROW")) == 0;
+    // an operand of at most 64 columns gets a 64-wide tile (one tile either way: the split count is unchanged)
+    const bool na = !one_team_env && !no_narrow && M <= 64, nb = !one_team_env && !no_narrow && N <= 64;
+    const int tm = na ? 1 : (M + TN_BM - 1) / TN_BM, tn = nb ? 1 : (N + TN_BN - 1) / TN_BN;
     // a two-team workgroup (80 KB of LDS) has a CU to itself: the grid must not exceed the CUs it may use, or its last
     // few workgroups run as a second round (258 workgroups for 6 tiles x 43 splits took 1.45x the time of 252); matrices
     // of more than 64 tiles would leave a quarter of the chip idle that way and keep the one-team form
     const bool one_team = one_team_env || tm * tn > 64;
-    static const bool no_narrow = getenv("PCB_TN_NARROW") && atoi(getenv("PCB_TN_NARROW")) == 0;
-    const bool narrow = !one_team && !no_narrow && M <= 64 && N <= 64;   // 64 x 64 tile, 64 rows per stage
     const long splits = pcb_tn_splits(R, M, N, &rps, one_team ? target : ((target / 2) / (tm * tn) > 0 ? (target / 2) / (tm * tn) : 1) * (tm * tn));
     const dim3 grid((unsigned)(tm * tn * splits));
     const long stride = (long)M * N + (colsum ? M : 0);
@@ -1280,13 +1294,26 @@ void launch_tn(const Operand &A, const Operand &B, int bpro, long R, int M, int 
             hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
         else
             hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT>), grid, dim3(256), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
-    } else if (narrow) {
-        if (colsum && APRO == PRO_PLAIN && bpro == PRO_PLAIN)
-            hipLaunchKernelGGL((gemm_tn_kernel<PRO_PLAIN, PRO_PLAIN, 1, 2, 64>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, stride, 1, 1);
-        else if (bpro == PRO_PLAIN)
-            hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN, 0, 2, 64>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, stride, 1, 1);
+    } else if (na || nb) {
+#define PCB_TN_LAUNCH(TA, TB)                                                                                                   \
+    do {                                                                                                                        \
+        if (colsum && APRO == PRO_PLAIN && bpro == PRO_PLAIN)                                                                   \
+            hipLaunchKernelGGL((gemm_tn_kernel<PRO_PLAIN, PRO_PLAIN, 1, 2, TA, TB>), grid, dim3(512), 0, st, A, B, R, M, N, rps, \
+                               part, stride, tm, tn);                                                                           \
+        else if (bpro == PRO_PLAIN)                                                                                             \
+            hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_PLAIN, 0, 2, TA, TB>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, \
+                               stride, tm, tn);                                                                                 \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT, 0, 2, TA, TB>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, \
+                               stride, tm, tn);                                                                                 \
+    } while (0)
+        if (na && nb)
+            PCB_TN_LAUNCH(64, 64);
+        else if (na)
+            PCB_TN_LAUNCH(64, 128);
         else
-            hipLaunchKernelGGL((gemm_tn_kernel<APRO, PRO_BNACT, 0, 2, 64>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, stride, 1, 1);
+            PCB_TN_LAUNCH(128, 64);
+#undef PCB_TN_LAUNCH
     } else if (colsum && APRO == PRO_PLAIN && bpro == PRO_PLAIN)
         hipLaunchKernelGGL((gemm_tn_kernel<PRO_PLAIN, PRO_PLAIN, 1, 2>), grid, dim3(512), 0, st, A, B, R, M, N, rps, part, stride, tm, tn);
     else if (bpro == PRO_PLAIN)
