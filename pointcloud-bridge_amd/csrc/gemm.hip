@@ -837,7 +837,7 @@ constexpr int AR_BLD = AR_BK + 8;
 constexpr int AR_OLD = 64 + 8;  // per-wave output staging: 32 rows x 64 columns
 
 template <int PRO, int KCH>  // KCH = K/8 chunks per row held in LDS: 16 (K <= 128) or 32 (K <= 256)
-__global__ __launch_bounds__(256, 2) void gemm_nt_ares_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
+__global__ __launch_bounds__(256, 3) void gemm_nt_ares_kernel(Operand A_arg, const u16 *__restrict__ Bw, long R,
                                                             int N, int K, u16 *__restrict__ out)
 {
     const Operand A = local_copy(A_arg);
@@ -846,7 +846,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ares_kernel(Operand A_arg, con
     constexpr int RPT = 256 / KCH;        // rows covered by one pass of the 256 threads
     __shared__ __attribute__((aligned(16))) u16 As[AR_BM * ALD];
     __shared__ __attribute__((aligned(16))) u16 Bs[AR_BN * AR_BLD];
-    __shared__ __attribute__((aligned(16))) u16 Os[4 * 32 * AR_OLD];
+    // the per-wave output staging blocks share the weight stage buffer (idle between a column tile's last barrier and the next
+    // tile's first stage; one more barrier per column tile): 52 instead of 71 KB at K = 256 -- three workgroups per CU
+    static_assert(4 * 32 * AR_OLD <= AR_BN * AR_BLD, "output staging must fit the weight stage");
+    u16 *const Os = Bs;
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -928,8 +931,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ares_kernel(Operand A_arg, con
                 if (r < R && n < N)
                     *reinterpret_cast<uint4 *>(out + r * N + n) = *reinterpret_cast<const uint4 *>(&stage[rr * AR_OLD + cc]);
             }
+            __syncthreads();  // the staging blocks are the weight stage buffer: read back before the next stage is parked
         }
-        __syncthreads();  // As is rebuilt for the next row tile
+        // (As is rebuilt for the next row tile: the barrier above covers it)
     }
 }
 
@@ -1381,7 +1385,9 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
         // wide input gradient: transformed A tile resident in LDS, column tiles walked inside
         const long tiles = (R + AR_BM - 1) / AR_BM;
         const long ares_chip = pcb_nt_grid_x(PRO_DY, (long)PCB_MAX_SLABS * NT_BM, NT_BN, pcb_busy_cus());  // the backward grid of a full chip
-        const dim3 grid((unsigned)(tiles < ares_chip ? tiles : ares_chip));
+        static const long ares_wgs = getenv("PCB_ARES_WGS") ? atol(getenv("PCB_ARES_WGS")) : 3;  // resident workgroups per CU
+        const long ares_grid = ares_chip * ares_wgs / 2;   // (ares_chip counts two per CU)
+        const dim3 grid((unsigned)(tiles < ares_grid ? tiles : ares_grid));
         if (pro == PRO_DY) {
             if (K <= 128)
                 hipLaunchKernelGGL((gemm_nt_ares_kernel<PRO_DY, 16>), grid, dim3(256), 0, st, A, (const u16 *)w, R, N, K, (u16 *)out);
