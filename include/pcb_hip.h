@@ -419,7 +419,27 @@ int pcb_gemm_nt_bias_add_bf16(const void *a, const void *w, const float *bias, c
  * pcb_dy_repeat_sums_bf16 is its backward towards the addends: d add_l[i] = sum of dy over the 2^sh_l rows coarse row i
  * stood for, dy rebuilt from (dz, y, BatchNorm-backward constants) as in pcb_dy_rows_bf16 (d2 may be NULL; sh2 >= sh1). */
 int pcb_gemm_nt_stats_add_bf16(const void *a, const void *w, long R, int N, int K, void *out, float *sums, int nparts,
-                               const float *add1, int sh1, const float *add2, int sh2, void *stream);
+                               const float *add1, int sh1, const float *add2, int sh2, const float *centre, void *stream);
+/* Centred storage of pre-BatchNorm rows (bf16 mode; reference semantics unchanged: models/pointnet2_utils.py:149-154,
+ * :207-209, :353-356 -- BatchNorm is invariant to a per-channel constant in front of it, exactly as it is to the conv
+ * bias).  A bf16 value carries an absolute error of 2^-9 |y| and train-mode BatchNorm divides by std(y): stored as is,
+ * the rounding error in units of the normalised signal is 2^-9 (|mean|/std + 1) per layer.  So the forward GEMM of a
+ * Conv+BatchNorm layer writes
+ *   out = bf16(A' W^T - centre[N])        (pro 0: A' = a;  1: A' = act(a*scale + shift); centre may be NULL)
+ * with the statistics slabs of THOSE rows (as pcb_gemm_nt_bf16 with sums), and pcb_bn_finalize_centred works on the
+ * centred moments: scale, shift, mean, invstd all live in the centred frame, which is the frame every consumer of y
+ * (operand prologues, pooling, BatchNorm backward) reads it in -- none of them changes.
+ * cmode 0: as pcb_bn_finalize.  Training, cmode 1: running_mean takes mean + centre (+ bias), then centre += mean in the
+ * channels where |mean| > std/4 (this batch's mean becomes the next call's centre; a centre that is close enough stays
+ * put, which keeps the rounding of y reproducible between two passes over the same batch).  Training, cmode 2 (probe): centre += mean and NOTHING else.  Eval,
+ * cmode 1: centre (an output) = running_mean - bias, mean = 0 -- run it BEFORE the GEMM, which subtracts centre.
+ * The same `centre` argument on pcb_gemm_nt_stats_add_bf16 and pcb_gather_add_bf16. */
+int pcb_gemm_nt_stats_bf16(int pro, const void *a, const float *scale, const float *shift, int act, const void *w, long R,
+                           int N, int K, void *out, float *sums, int nparts, const float *centre, void *stream);
+int pcb_bn_finalize_centred(const float *sums, int nparts, long rows, long count, int C, const float *gamma,
+                            const float *beta, const float *bias, float *running_mean, float *running_var, float momentum,
+                            float eps, int training, float *scale, float *shift, float *mean, float *invstd,
+                            long long *num_batches_tracked, float *centre, int cmode, void *stream);
 int pcb_dy_repeat_sums_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *p,
                             const float *q, int act, long R, int C, int sh1, float *d1, int sh2, float *d2, void *stream);
 int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
@@ -649,7 +669,7 @@ int pcb_attention_fwd_bf16(const void *qkv, int B, int N, int H, int D, float sc
  * from native code keeps the host ahead of the GPU (one foreign call per stack and direction).
  * dtype selects the row type (pcb_dtype) of x, y, out, g, dx, dzbuf and wbuf; the sequence is the same.
  *
- * desc: L x 16 int64 on the HOST, per layer
+ * desc: L x PCB_STACK_DESC_SLOTS (18) int64 on the HOST, per layer
  *   [0] w fp32 [C,k]  [1] conv bias [C] or 0  [2] gamma or 0  [3] beta or 0
  *   [4] running_mean or 0  [5] running_var or 0  [6] C (multiple of 8 / 4)  [7] k = real input columns
  *   [8] 1: batch statistics (training), 0: running statistics
@@ -660,6 +680,13 @@ int pcb_attention_fwd_bf16(const void *qkv, int B, int N, int H, int D, float sc
  *        {add1, sh1, add2 or 0, sh2, d add1, d add2, row stride of w in floats or 0}: the layer's GEMM is
  *        pcb_gemm_nt_stats_add_bf16 (forward), backward also writes d add1 / d add2 where given
  *        (pcb_dy_repeat_sums_bf16); w may be a column slice of a wider weight (its rows `stride` floats apart)
+ *   [16] centre: fp32 [C] the caller keeps ACROSS calls for this BatchNorm layer, or 0.  bf16 rows, forward, training
+ *        mode: y is stored as bf16(x W^T - centre) and the finalize kernel moves centre to this batch's mean (see
+ *        pcb_gemm_nt_stats_bf16 / pcb_bn_finalize_centred); backward needs nothing (every constant it reads lives in
+ *        the centred frame).  Ignored for fp32 rows.
+ *   [17] centre flags: bit 0 = the buffer holds no estimate yet (zeros): GEMM + finalize run once to learn the batch
+ *        mean, then again centred on it (under `sync` both finalize passes all-reduce: the mean is the global one);  bit 1 = an EVAL-mode layer stores y centred on
+ *        running_mean - bias (kept in row 0 of its stz block)
  * fdesc: L x 2 doubles: momentum, eps.  stat_repeat >= 1: every row of x stands for that many
  * identical samples (see pcb_bn_finalize `count`); 1 otherwise.
  * x [R,Kp] rows in the column layout `perm` (see pcb_prep_weights_*); act 0/1/2;
@@ -687,6 +714,7 @@ int pcb_attention_fwd_bf16(const void *qkv, int B, int N, int H, int D, float sc
  * dx [R,Kp] or NULL.
  */
 #define PCB_STACK_MAX_LAYERS 16
+#define PCB_STACK_DESC_SLOTS 18
 typedef struct pcb_sync {
     int (*allreduce)(float *buf, int n, void *ctx);
     void *ctx;
@@ -732,7 +760,7 @@ int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, const void *
 int pcb_gather_add_partials(long R, int C);
 int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S, int ns, int C,
                         const float *xyz, const float *ctr, const float *wx, int ldw, void *y, float *sums,
-                        int nparts, void *stream);
+                        int nparts, const float *centre, void *stream);
 int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *scale, const float *shift,
                         const float *p, const float *q, const float *dout, const unsigned char *argmax, int act,
                         const int64_t *idx, int B, int N, int S, int ns, int C, const float *xyz,

@@ -85,7 +85,7 @@ SIGNATURES = {
     "pcb_mlp_stack_forward": [_i, _i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "pcb_mlp_stack_backward": [_i, _i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
     "pcb_gather_add_partials": [_l, _i],
-    "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p],
+    "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p],
     "pcb_scatter_dy_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "pcb_gate_bf16": [_p, _p, _p, _l, _p],
     "pcb_gate_f32": [_p, _p, _p, _l, _p],
@@ -120,7 +120,9 @@ SIGNATURES = {
     "pcb_prep_weights_table_f32": [_p, _i, _l, _p],
     "pcb_mlp_stack_dzbuf_elems": [_i, _i, _p, _l, _i, _i, _i],
     "pcb_dy_rows_bf16": [_p, _p, _p, _p, _p, _p, _i, _l, _i, _p, _p],
-    "pcb_gemm_nt_stats_add_bf16": [_p, _p, _l, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p],
+    "pcb_gemm_nt_stats_add_bf16": [_p, _p, _l, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p],
+    "pcb_gemm_nt_stats_bf16": [_i, _p, _p, _p, _i, _p, _l, _i, _i, _p, _p, _i, _p, _p],
+    "pcb_bn_finalize_centred": [_p, _i, _l, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "pcb_dy_repeat_sums_bf16": [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p, _p],
     "pcb_copy_table": [_p, _i, _l, _p],
     "pcb_pad_rows_bf16": [_p, _l, _l, _i, _i, _p, _p],

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(kThreads) void gather_add_kernel(const float *__res
                                                                float *__restrict__ sums,
                                                                const float *__restrict__ xyz,
                                                                const float *__restrict__ ctr,
-                                                               const float *__restrict__ wx, int ldw)
+                                                               const float *__restrict__ wx, int ldw,
+                                                               const float *__restrict__ centre)
 {
     __shared__ float red[kThreads * 16];
     const int CT = C >> 3;
@@ -67,6 +68,9 @@ __global__ __launch_bounds__(kThreads) void gather_add_kernel(const float *__res
         w1[i] = on ? wx[(long)(cc * 8 + i) * ldw + 1] : 0.0f;
         w2[i] = on ? wx[(long)(cc * 8 + i) * ldw + 2] : 0.0f;
     }
+    float ce[8];   // rows stored centred (see gemm.hip RedArgs::centre); NULL: no centring
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ce[i] = (centre != nullptr && rl < RT) ? centre[cc * 8 + i] : 0.0f;
     if (rl < RT) {
         for (long r = (long)blockIdx.x * RT + rl; r < R; r += (long)gridDim.x * RT) {
             const long b = r / per_scene;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void gather_add_kernel(const float *__res
             uint32_t w[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const u16 lo = f2bf(a[2 * i] + c[2 * i]), hi = f2bf(a[2 * i + 1] + c[2 * i + 1]);
+                const u16 lo = f2bf((a[2 * i] + c[2 * i]) - ce[2 * i]), hi = f2bf((a[2 * i + 1] + c[2 * i + 1]) - ce[2 * i + 1]);
                 w[i] = (uint32_t)lo | ((uint32_t)hi << 16);
                 const float f0 = bf2f(lo), f1 = bf2f(hi);  // statistics of the values the next kernels read
                 s[2 * i] += f0;
@@ -232,7 +236,7 @@ extern "C" int pcb_gather_add_partials(long R, int C)
 
 extern "C" int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S,
                                    int ns, int C, const float *xyz, const float *ctr, const float *wx, int ldw,
-                                   void *y, float *sums, int nparts, void *stream)
+                                   void *y, float *sums, int nparts, const float *centre, void *stream)
 {
     if (!u || !idx || !y || !sums || B <= 0 || N <= 0 || S <= 0 || ns <= 0) return PCB_ERR_INVALID_ARG;
     if (nparts < 1 || nparts > 1024) return PCB_ERR_INVALID_ARG;  // the caller's slab count IS the grid
@@ -240,7 +244,7 @@ extern "C" int pcb_gather_add_bf16(const float *u, const float *v, const int64_t
     if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
     const long R = (long)B * S * ns;
     hipLaunchKernelGGL(gather_add_kernel, dim3((unsigned)nparts), dim3(kThreads), 0,
-                       (hipStream_t)stream, u, v, idx, N, S, ns, C, R, (u16 *)y, sums, xyz, ctr, wx, ldw);
+                       (hipStream_t)stream, u, v, idx, N, S, ns, C, R, (u16 *)y, sums, xyz, ctr, wx, ldw, centre);
     pcb_account(6.0 * R * C + 8.0 * R + (v ? 4.0 * B * S * C : 0.0));
     return pcb_check_launch();
 }

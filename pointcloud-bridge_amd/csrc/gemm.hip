@@ -227,6 +227,11 @@ struct RedArgs {
     // product is computed on their own rows and arrives here instead of as 2^sh copies in the A operand.
     const float *add1, *add2;
     int sh1, sh2;
+    // STATS: out = bf16(A'.W^T [+ addends] - centre[N]) -- the layer's pre-BatchNorm rows are stored CENTRED on a per-column
+    // constant close to their batch mean (BatchNorm is invariant to it: the finalize kernel works on the centred moments and
+    // adds it back for running_mean).  A bf16 value carries an absolute error of 2^-9 |y| and BatchNorm divides by std(y): stored
+    // uncentred, the error in units of the normalised signal is 2^-9 (|mean|/std + 1).  NULL: no centring.
+    const float *centre;
 };
 
 template <int PRO, int STATS, int RED, int OUT32 = 0>
@@ -394,10 +399,14 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
                 const int n = n0 + j * 32 + (lane & 31);
                 bj = n < N ? red_arg.bias[n] : 0.0f;
             }
+            if (STATS && red_arg.centre) {   // (wave-uniform) rows stored centred: see RedArgs
+                const int n = n0 + j * 32 + (lane & 31);
+                bj = n < N ? -red_arg.centre[n] : 0.0f;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                const u16 h = f2bf((!STATS && !RED) ? acc[j][i] + bj : acc[j][i]);
+                const u16 h = f2bf(!RED ? acc[j][i] + bj : acc[j][i]);
                 stage[rr * NT_OUT_LD + j * 32 + (lane & 31)] = h;
                 if (STATS) {
                     const float v = bf2f(h);  // statistics of the values the next kernels will read
@@ -490,6 +499,14 @@ __global__ __launch_bounds__(256, (PRO <= PRO_BNACT ? 3 : 2)) void gemm_nt_kerne
             for (int w = 0; w < 4; ++w) {
                 a += ssum[(w * 2 + 0) * NT_BN + t];
                 b += ssum[(w * 2 + 1) * NT_BN + t];
+            }
+            if (STATS && red_arg.centre && (long)blockIdx.x == (tiles_m - 1) % (long)gridDim.x) {
+                // rows past R: their accumulators are exact zeros, so the centred epilogue turned each of them into
+                // bf16(-centre) (never stored: the buffer store drops them) -- taken out of the statistics again here, by
+                // the workgroup that handled the last row tile, instead of a select per element in every tile
+                const float pad = (float)(tiles_m * NT_BM - R), v = bf2f(f2bf(-red_arg.centre[n0 + t]));
+                a -= pad * v;
+                b -= pad * (v * v);
             }
             sums[((long)blockIdx.x * 2 + 0) * N + n0 + t] = a;
             sums[((long)blockIdx.x * 2 + 1) * N + n0 + t] = b;
@@ -708,6 +725,10 @@ __global__ __launch_bounds__(WM * 128, OCC) void gemm_nt8_kernel(Operand A_arg, 
                 const int n = n0 + wn * 64 + j * 32 + (lane & 31);
                 bj = n < N ? red_arg.bias[n] : 0.0f;
             }
+            if (STATS && red_arg.centre) {   // (wave-uniform) rows stored centred: see RedArgs
+                const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+                bj = n < N ? -red_arg.centre[n] : 0.0f;
+            }
             float ad[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (STATS == 2) {
                 // the lane's 16 accumulators are 4 runs of 4 consecutive rows (aligned to 4): one coarse row each
@@ -725,7 +746,7 @@ __global__ __launch_bounds__(WM * 128, OCC) void gemm_nt8_kernel(Operand A_arg, 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                const u16 h = f2bf((!STATS && !RED) ? acc[j][i] + bj : (STATS == 2 ? acc[j][i] + ad[i >> 2] : acc[j][i]));
+                const u16 h = f2bf(RED ? acc[j][i] : (STATS == 2 ? (acc[j][i] + ad[i >> 2]) + bj : acc[j][i] + bj));
                 stg[rr * OLD + j * 32 + (lane & 31)] = h;
                 if (STATS) {
                     const float v = bf2f(h);
@@ -820,6 +841,12 @@ __global__ __launch_bounds__(WM * 128, OCC) void gemm_nt8_kernel(Operand A_arg, 
             for (int w = 0; w < WM; ++w) {
                 a += ssum[(w * 2 + 0) * NT_BN + t];
                 b += ssum[(w * 2 + 1) * NT_BN + t];
+            }
+            if (STATS && red_arg.centre && (long)blockIdx.x == (tiles_m - 1) % (long)gridDim.x) {
+                // rows past R took bf16(-centre) in the centred epilogue (see gemm_nt_kernel): out of the statistics again
+                const float pad = (float)(tiles_m * BM - R), v = bf2f(f2bf(-red_arg.centre[n0 + t]));
+                a -= pad * v;
+                b -= pad * (v * v);
             }
             sums[((long)blockIdx.x * 2 + 0) * N + n0 + t] = a;
             sums[((long)blockIdx.x * 2 + 1) * N + n0 + t] = b;
@@ -1244,13 +1271,14 @@ __global__ __launch_bounds__(256) void dy_repeat_sums_kernel(Operand A_arg, long
 
 template <int PRO>
 void launch_nt(const Operand &A, const u16 *Bw, long R, int N, int K, u16 *out, float *sums, int nparts, hipStream_t st,
-               const RedArgs *red = nullptr)
+               const RedArgs *red = nullptr, const float *centre = nullptr)
 {
     // with slabs the caller's count IS the grid (it sized its buffer and its finalize call for it);
     // without, the resident-workgroup preference for the hint in force now
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)(sums ? nparts : pcb_nt_grid_x(PRO, R, N, pcb_busy_cus())), ny);
     RedArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    none.centre = sums ? centre : nullptr;
     // the eight-wave form: its LDS constants limit K for the BatchNorm-on-load prologue only (plain rows: any K)
     if (PRO == PRO_PLAIN || (PRO == PRO_BNACT && K <= N8_MAXK)) {
         // forward prologues: the eight-wave form, two workgroups per CU
@@ -1412,6 +1440,29 @@ extern "C" int pcb_gemm_nt_bf16(int pro, const void *a0, const void *a1, const f
     return pcb_check_launch();
 }
 
+// The forward GEMM of a Conv + BatchNorm layer with its rows stored CENTRED: out = bf16(A'.W^T - centre[N]) and the
+// statistics slabs of those rows (pro 0 plain / 1 BatchNorm+activation of the previous layer on load).  See RedArgs.
+extern "C" int pcb_gemm_nt_stats_bf16(int pro, const void *a, const float *scale, const float *shift, int act,
+                                      const void *w, long R, int N, int K, void *out, float *sums, int nparts,
+                                      const float *centre, void *stream)
+{
+    if (!a || !w || !out || !sums || R <= 0) return PCB_ERR_INVALID_ARG;
+    if (nparts < 1 || nparts > PCB_MAX_SLABS) return PCB_ERR_INVALID_ARG;
+    if (bad_dim(N) || bad_dim(K)) return PCB_ERR_UNSUPPORTED;
+    if (pro != PRO_PLAIN && pro != PRO_BNACT) return PCB_ERR_INVALID_ARG;
+    if (pro == PRO_BNACT && (!scale || !shift)) return PCB_ERR_INVALID_ARG;
+    const Operand A = make_operand(a, nullptr, K, scale, shift, nullptr, nullptr, nullptr, nullptr, 1, act);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
+    if (pro == PRO_PLAIN)
+        launch_nt<PRO_PLAIN>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, nparts, st, nullptr, centre);
+    else
+        launch_nt<PRO_BNACT>(A, (const u16 *)w, R, N, K, (u16 *)out, sums, nparts, st, nullptr, centre);
+    pcb_timer_end(st, timed, nt_bytes(pro, R, N, K, 1), pro, R, N, K);
+    return pcb_check_launch();
+}
+
 extern "C" int pcb_dy_rows_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *p,
                                 const float *q, int act, long R, int C, void *dy, void *stream)
 {
@@ -1516,7 +1567,8 @@ extern "C" int pcb_gemm_nt_bias_add_bf16(const void *a, const void *w, const flo
 // as the A operand: out = bf16(x W^T + add1[r >> sh1] + add2[r >> sh2]) and the column sums / sums of squares of out
 // as slabs (one per workgroup along x, nparts of them), see RedArgs.  add2 may be NULL.
 extern "C" int pcb_gemm_nt_stats_add_bf16(const void *a, const void *w, long R, int N, int K, void *out, float *sums,
-                                          int nparts, const float *add1, int sh1, const float *add2, int sh2, void *stream)
+                                          int nparts, const float *add1, int sh1, const float *add2, int sh2,
+                                          const float *centre, void *stream)
 {
     if (!a || !w || !out || !sums || !add1 || R <= 0) return PCB_ERR_INVALID_ARG;
     if (nparts < 1 || nparts > PCB_MAX_SLABS) return PCB_ERR_INVALID_ARG;
@@ -1526,7 +1578,7 @@ extern "C" int pcb_gemm_nt_stats_add_bf16(const void *a, const void *w, long R, 
     const Operand A = make_operand(a, nullptr, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0);
     const unsigned ny = (unsigned)((N + NT_BN - 1) / NT_BN);
     const dim3 grid((unsigned)nparts, ny);
-    const RedArgs epi = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, add1, add2, sh1, add2 ? sh2 : sh1};
+    const RedArgs epi = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, add1, add2, sh1, add2 ? sh2 : sh1, centre};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);

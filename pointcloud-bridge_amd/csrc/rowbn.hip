@@ -128,12 +128,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float *__restrict__ beta, const float *__restrict__ bias, float *__restrict__ running_mean,
     float *__restrict__ running_var, float momentum, float eps, int training, float *__restrict__ scale,
     float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out,
-    long long *__restrict__ num_batches_tracked)
+    long long *__restrict__ num_batches_tracked, float *__restrict__ centre, int cmode)
 {
+    // centre / cmode: the rows were stored CENTRED, y_c = x W^T - centre (gemm.hip RedArgs::centre), and `sums` are the
+    // moments of y_c.  Everything downstream (scale, shift, mean, invstd -> the consumers' prologues, the backward
+    // constants) lives in that frame and needs no change; only running_mean wants the true mean back.
+    //   training, cmode 1: running_mean from mean_c + centre (+ bias); then, where |mean_c| > std/4, centre += mean_c -- this
+    //                      batch's mean is the next step's centre (a persistent per-layer buffer of the caller)
+    //   training, cmode 2: PROBE -- centre += mean_c and nothing else (the caller then runs the GEMM again with a centre
+    //                      that is this batch's mean: the first step of a fresh layer)
+    //   eval,     cmode 1: centre (output, the caller's scratch) = running_mean - bias, the exact centre; the GEMM that
+    //                      follows subtracts it, so mean_y = 0 in that frame
     __shared__ double red[2][32][32];
     // nn.BatchNorm's step counter (num_batches_tracked += 1 in a train-mode forward), bumped here
     // instead of by one more tiny launch per module
-    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    if (num_batches_tracked && cmode != 2 && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
@@ -169,6 +178,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
         s2 += red[1][k][cl];
     }
     const float b = bias ? bias[c] : 0.0f;
+    const float ce = (centre && cmode && training) ? centre[c] : 0.0f;
     float mean_y, invstd;
     if (training) {
         const double n = (double)rows;
@@ -177,15 +187,24 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
         var = var < 0.0 ? 0.0 : var;
         mean_y = (float)mu;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
+        // hysteresis: the centre only has to be within a fraction of a standard deviation of the mean, and a centre that
+        // does not move from step to step keeps the rounding of y -- and with it everything downstream -- reproducible
+        // between two passes over the same batch (an eager step and the replays of its captured twin, a repeated test)
+        if (centre && cmode && (cmode == 2 || fabsf(mean_y) * invstd > 0.25f)) centre[c] = ce + mean_y;
+        if (cmode == 2) return;
         if (running_mean) {
             const double m = (double)count;
             const float unb = (float)(count > 1 ? var * (m / (m - 1.0)) : var);
-            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (mean_y + b);
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * ((mean_y + ce) + b);
             running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unb;
         }
     } else {
         mean_y = running_mean[c] - b;  // BN(y + b) with running stats == (y - (rm - b)) * invstd
         invstd = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+        if (centre && cmode) {
+            centre[c] = mean_y;
+            mean_y = 0.0f;
+        }
     }
     const float g = gamma ? gamma[c] : 1.0f;
     const float sc = g * invstd;
@@ -758,17 +777,27 @@ int pcb_sum_slabs(const float *slabs, int nparts, int n, float *out, void *strea
     return pcb_check_launch();
 }
 
+int pcb_bn_finalize_centred(const float *sums, int nparts, long rows, long count, int C, const float *gamma,
+                            const float *beta, const float *bias, float *running_mean, float *running_var, float momentum,
+                            float eps, int training, float *scale, float *shift, float *mean, float *invstd,
+                            long long *num_batches_tracked, float *centre, int cmode, void *stream)
+{
+    if (!scale || !shift || !mean || !invstd || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
+    if (training ? (!sums || nparts < 1) : (!running_mean || !running_var)) return PCB_ERR_INVALID_ARG;
+    if (cmode < 0 || cmode > 2 || (cmode && !centre) || (cmode == 2 && !training)) return PCB_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, nparts,
+                       rows, count > 0 ? count : rows, C, gamma, beta, bias, running_mean, running_var, momentum, eps, training,
+                       scale, shift, mean, invstd, num_batches_tracked, centre, cmode);
+    return pcb_check_launch();
+}
+
 int pcb_bn_finalize(const float *sums, int nparts, long rows, long count, int C, const float *gamma,
                     const float *beta, const float *bias, float *running_mean, float *running_var, float momentum,
                     float eps, int training, float *scale, float *shift, float *mean, float *invstd,
                     long long *num_batches_tracked, void *stream)
 {
-    if (!scale || !shift || !mean || !invstd || C <= 0 || rows <= 0) return PCB_ERR_INVALID_ARG;
-    if (training ? (!sums || nparts < 1) : (!running_mean || !running_var)) return PCB_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, sums, nparts,
-                       rows, count > 0 ? count : rows, C, gamma, beta, bias, running_mean, running_var, momentum, eps, training,
-                       scale, shift, mean, invstd, num_batches_tracked);
-    return pcb_check_launch();
+    return pcb_bn_finalize_centred(sums, nparts, rows, count, C, gamma, beta, bias, running_mean, running_var, momentum, eps,
+                                   training, scale, shift, mean, invstd, num_batches_tracked, nullptr, 0, stream);
 }
 
 int pcb_bn_act_bf16(const void *y, const float *scale, const float *shift, long rows, int C, int act, void *z, void *stream)

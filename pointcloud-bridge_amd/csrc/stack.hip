@@ -181,8 +181,17 @@ extern "C" int pcb_timer_read(int category, long *launches, double *milliseconds
 
 // ---- stack descriptors ------------------------------------------------------------------------
 namespace {
-constexpr int kSlots = 16;  // int64 slots per layer, see include/pcb_hip.h
-enum { S_W = 0, S_BIAS, S_GAMMA, S_BETA, S_RMEAN, S_RVAR, S_C, S_K, S_TRAIN, S_Y, S_DW, S_DGAMMA, S_DBETA, S_DBIAS, S_NBT, S_EXT };
+constexpr int kSlots = PCB_STACK_DESC_SLOTS;  // int64 slots per layer, see include/pcb_hip.h
+enum { S_W = 0, S_BIAS, S_GAMMA, S_BETA, S_RMEAN, S_RVAR, S_C, S_K, S_TRAIN, S_Y, S_DW, S_DGAMMA, S_DBETA, S_DBIAS, S_NBT, S_EXT,
+       S_CENTRE, S_CFLAGS };
+static_assert(kSlots == 18, "descriptor layout");
+// S_CENTRE / S_CFLAGS (bf16 rows, forward only): the layer's y is stored centred (gemm.hip RedArgs::centre).
+//   S_CENTRE  fp32 [C] owned by the caller across calls (one per BatchNorm layer) or 0: the centre of a TRAINING-mode layer,
+//             read by its GEMM, moved to this batch's mean by its finalize kernel;
+//   S_CFLAGS  bit 0 PROBE: the buffer holds no estimate yet (zeros): the layer runs GEMM + finalize once to learn the batch
+//             mean and once more centred on it;  bit 1: centre an EVAL-mode layer on running_mean - bias (kept in row 0 of
+//             the layer's stz block; its finalize kernel then runs BEFORE its GEMM).
+enum { CF_PROBE = 1, CF_EVAL = 2 };
 // S_EXT (layer 0 of a plain bf16 stack only): host address of 7 int64 or 0 --
 //   [0] add1, [1] sh1, [2] add2 (or 0), [3] sh2: fp32 rows [R >> sh, C] added to the layer's product before rounding, each
 //       standing for 2^sh consecutive rows (pcb_gemm_nt_stats_add_bf16);  [4] d add1, [5] d add2: their gradients (backward);
@@ -197,6 +206,8 @@ struct Layer {
     float *dW, *dgamma, *dbeta, *dbias;
     long long *nbt;  // num_batches_tracked or NULL
     const long long *ext;  // S_EXT or NULL
+    float *centre;   // S_CENTRE or NULL
+    int cflags;      // S_CFLAGS
     int kp;          // padded input width (= previous layer's C, or the stack's Kp)
     long wp_off;     // element offsets into the weight buffer
     long wt_off;     // -1: no transposed copy
@@ -252,6 +263,8 @@ int parse(int L, const long long *desc, int Kp, int need_wt0, bool gathered, int
         a.dbias = ptr<float>(d[S_DBIAS]);
         a.nbt = ptr<long long>(d[S_NBT]);
         a.ext = ptr<const long long>(d[S_EXT]);
+        a.centre = ptr<float>(d[S_CENTRE]);
+        a.cflags = (int)d[S_CFLAGS];
         if (a.ext && (l > 0 || gathered)) return PCB_ERR_INVALID_ARG;
         if (gathered && l == 0) {
             // layer 0 = gather_add of per-point products: no weights of its own in this call
@@ -469,29 +482,18 @@ extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, co
         if (stats && !parts) return PCB_ERR_INVALID_ARG;
         const float *pscale = l ? row(stz, ly[l - 1], 2) : nullptr;
         const float *pshift = l ? row(stz, ly[l - 1], 3) : nullptr;
-        int nparts;
-        if (gathered && l == 0) {
-            const int want = pcb_gather_add_partials(R, a.C);
-            nparts = want < parts_slabs ? want : parts_slabs;
-            PCB_TRY(pcb_gather_add_bf16(ga.u, ga.v, ga.idx, ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.wx, ga.ldw,
-                                        a.y, parts, nparts, stream));
-        } else if (a.ext && a.ext[X_ADD1]) {
-            // the coarse levels of a repeated concatenation arrive as addends of the product (see S_EXT); the statistics
-            // epilogue runs in eval mode too (its slabs are then ignored)
-            if (dtype != PCB_DTYPE_BF16) return PCB_ERR_UNSUPPORTED;
-            if (!parts) return PCB_ERR_INVALID_ARG;
-            nparts = slabs_for(0, R, a.C, busy, parts_slabs);
-            PCB_TRY(pcb_gemm_nt_stats_add_bf16(cur, wb + a.wp_off * op.elem, R, a.C, a.kp, a.y, parts, nparts,
-                                               ptr<const float>(a.ext[X_ADD1]), (int)a.ext[X_SH1],
-                                               ptr<const float>(a.ext[X_ADD2]), (int)a.ext[X_SH2], stream));
-        } else {
-            nparts = stats ? slabs_for(l ? 1 : 0, R, a.C, busy, parts_slabs) : 0;
-            PCB_TRY(op.gemm_nt(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0, act,
-                               wb + a.wp_off * op.elem, R, a.C, a.kp, a.y, stats ? parts : nullptr, nparts, stream));
-        }
-        if (!ready) {
+        // rows stored centred (bf16 rows only): a training-mode layer on the caller's persistent estimate of its batch mean,
+        // an eval-mode layer on running_mean - bias (row 0 of its constants, written by its finalize kernel first)
+        const bool bf16 = dtype == PCB_DTYPE_BF16;
+        float *centre = nullptr;
+        if (bf16 && stats && a.centre) centre = a.centre;
+        const bool eval_centre = bf16 && !stats && (a.cflags & CF_EVAL) && a.rmean && a.rvar;
+        if (eval_centre) centre = row(stz, a, 0);
+        int nparts = 0;
+        auto finalize = [&](int cmode) -> int {
             const float *sums = stats ? parts : nullptr;
             long rows = R;
+            int np = nparts;
             if (stats && sync) {
                 // SyncBatchNorm: the local totals (2C floats) travel through the caller's all-reduce;
                 // the finalize kernel then sees the statistics of all ranks' rows
@@ -499,13 +501,53 @@ extern "C" int pcb_mlp_stack_forward(int dtype, int L, const long long *desc, co
                 PCB_TRY(pcb_sum_slabs(parts, nparts, 2 * a.C, tot, stream));
                 if (sync->allreduce(tot, 2 * a.C, sync->ctx) != 0) return PCB_ERR_LAUNCH;
                 sums = tot;
-                nparts = 1;
+                np = 1;
                 rows = sync->global_rows;
             }
-            PCB_TRY(pcb_bn_finalize(sums, nparts, rows, rows * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma,
-                                    a.beta, a.bias, a.rmean, a.rvar, (float)fdesc[2 * l], (float)fdesc[2 * l + 1],
-                                    a.training, row(stz, a, 2), row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), a.nbt,
-                                    stream));
+            return pcb_bn_finalize_centred(sums, np, rows, rows * (stat_repeat > 1 ? stat_repeat : 1), a.C, a.gamma, a.beta,
+                                           a.bias, a.rmean, a.rvar, (float)fdesc[2 * l], (float)fdesc[2 * l + 1], a.training,
+                                           row(stz, a, 2), row(stz, a, 3), row(stz, a, 4), row(stz, a, 5), a.nbt, centre,
+                                           cmode, stream);
+        };
+        auto produce = [&]() -> int {
+            if (gathered && l == 0) {
+                const int want = pcb_gather_add_partials(R, a.C);
+                nparts = want < parts_slabs ? want : parts_slabs;
+                return pcb_gather_add_bf16(ga.u, ga.v, ga.idx, ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.wx, ga.ldw, a.y,
+                                           parts, nparts, centre, stream);
+            }
+            if (a.ext && a.ext[X_ADD1]) {
+                // the coarse levels of a repeated concatenation arrive as addends of the product (see S_EXT); the statistics
+                // epilogue runs in eval mode too (its slabs are then ignored)
+                if (!bf16) return PCB_ERR_UNSUPPORTED;
+                if (!parts) return PCB_ERR_INVALID_ARG;
+                nparts = slabs_for(0, R, a.C, busy, parts_slabs);
+                return pcb_gemm_nt_stats_add_bf16(cur, wb + a.wp_off * op.elem, R, a.C, a.kp, a.y, parts, nparts,
+                                                  ptr<const float>(a.ext[X_ADD1]), (int)a.ext[X_SH1],
+                                                  ptr<const float>(a.ext[X_ADD2]), (int)a.ext[X_SH2], centre, stream);
+            }
+            if (centre) {
+                // (an eval-mode layer has no use for the slabs, but the centred epilogue is the statistics epilogue)
+                if (!parts) return PCB_ERR_INVALID_ARG;
+                nparts = slabs_for(l ? 1 : 0, R, a.C, busy, parts_slabs);
+                return pcb_gemm_nt_stats_bf16(l ? 1 : 0, cur, pscale, pshift, act, wb + a.wp_off * op.elem, R, a.C, a.kp, a.y,
+                                              parts, nparts, centre, stream);
+            }
+            nparts = stats ? slabs_for(l ? 1 : 0, R, a.C, busy, parts_slabs) : 0;
+            return op.gemm_nt(l ? 1 : 0, cur, nullptr, pscale, pshift, nullptr, nullptr, nullptr, nullptr, 0, act,
+                              wb + a.wp_off * op.elem, R, a.C, a.kp, a.y, stats ? parts : nullptr, nparts, stream);
+        };
+        if (eval_centre) {
+            // eval mode: the constants do not depend on the rows -- finalize first (it writes the centre), then the GEMM
+            if (!ready) PCB_TRY(finalize(1));
+            PCB_TRY(produce());
+        } else {
+            if (centre && (a.cflags & CF_PROBE)) {
+                PCB_TRY(produce());
+                PCB_TRY(finalize(2));
+            }
+            PCB_TRY(produce());
+            if (!ready) PCB_TRY(finalize(centre ? 1 : 0));
         }
         cur = a.y;
     }

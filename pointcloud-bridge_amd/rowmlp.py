@@ -22,6 +22,7 @@ nn.SyncBatchNorm layers all-reduce their statistics over the process group (para
 """
 import ctypes
 import os
+import threading
 import weakref
 
 import torch
@@ -33,7 +34,6 @@ from . import _lib
 from .ops import _launch, apply_concurrency_hint, on_device
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-_PRECISION = "fp32"
 
 
 class _Mode:
@@ -48,25 +48,84 @@ class _Mode:
 
 _MODES = {"bf16": _Mode(torch.bfloat16, 8, "bf16", 0), "fp32": _Mode(torch.float32, 4, "f32", 1)}
 
+# The row type in force is SCOPED, not global: a stack of `precision(...)` contexts per thread on top of a process-wide
+# default.  A module (a whole network, one set-abstraction level) carries its own precision through
+# bind_precision(module, mode): its forward pass then runs inside that context, whatever surrounds it, so two
+# networks of different precision interleave in one process and threads do not see each other's choice.  The
+# backward pass of every autograd function uses the row type its forward pass ran in (saved per call).
+_DEFAULT_PRECISION = "fp32"
+_tls = threading.local()
 
-def set_precision(mode):
-    """'fp32' (parity mode) or 'bf16' (throughput mode) rows for the fused MLP engine."""
-    global _PRECISION
+
+def _check_precision(mode):
     if mode not in _MODES:
         raise ValueError(f"precision must be 'fp32' or 'bf16', got {mode!r}")
-    _PRECISION = mode
+    return mode
+
+
+def set_precision(mode):
+    """Process-wide DEFAULT row type: 'fp32' (parity mode) or 'bf16' (throughput mode).  Scopes opened with
+    `precision(...)` and modules bound with bind_precision() take precedence."""
+    global _DEFAULT_PRECISION
+    _DEFAULT_PRECISION = _check_precision(mode)
+
+
+class precision:
+    """Context manager: the row type of every engine call made inside it by this thread; restores on exit.
+        with rowmlp.precision("bf16"):
+            logits = model(xyz, colors)"""
+
+    def __init__(self, mode):
+        self.mode = _check_precision(mode)
+
+    def __enter__(self):
+        stack = getattr(_tls, "stack", None)
+        if stack is None:
+            stack = _tls.stack = []
+        stack.append(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.stack.pop()
+        return False
+
+
+def bind_precision(module, mode):
+    """Make `mode` ('fp32' / 'bf16', None removes the binding) a property of `module`: its forward pass (and everything it
+    calls) runs in that row type regardless of the surrounding scope or default.  Returns the module."""
+    for h in getattr(module, "_pcb_precision_hooks", ()):
+        h.remove()
+    module._pcb_precision_hooks = ()
+    module.pcb_precision = None
+    if mode is None:
+        return module
+    module.pcb_precision = _check_precision(mode)
+
+    def enter(mod, args):
+        stack = getattr(_tls, "stack", None)
+        if stack is None:
+            stack = _tls.stack = []
+        stack.append(mod.pcb_precision)
+
+    def leave(mod, args, out):
+        _tls.stack.pop()
+
+    module._pcb_precision_hooks = (module.register_forward_pre_hook(enter),
+                                   module.register_forward_hook(leave, always_call=True))
+    return module
 
 
 def get_precision():
-    return _PRECISION
+    stack = getattr(_tls, "stack", None)
+    return stack[-1] if stack else _DEFAULT_PRECISION
 
 
 def is_bf16():
-    return _PRECISION == "bf16"
+    return get_precision() == "bf16"
 
 
 def mode():
-    return _MODES[_PRECISION]
+    return _MODES[get_precision()]
 
 
 def pad_cols(k):
@@ -322,7 +381,7 @@ def prepare_step():
 def _eval_lookup(layers, first, extra):
     """(key, versions, cached buffers or None) for a no-grad call whose layers are all in eval mode."""
     versions = tuple([t._version for lay in layers for t in lay[:6] if t is not None]) + (first.data_ptr(), _generation)
-    key = (id(first),) + extra
+    key = (id(first), _centring) + extra
     hit = _eval_operands.get(key)
     if hit is not None and hit[0]() is first and hit[1] == versions:
         return key, versions, hit[2]
@@ -396,6 +455,76 @@ def _sync_group(bns):
     return True, group
 
 
+# ---------------------------------------------------------------------------------------------
+# bf16 rows: pre-BatchNorm outputs stored CENTRED (include/pcb_hip.h: pcb_gemm_nt_stats_bf16).
+# A bf16 value carries an absolute error of 2^-9 |y| and train-mode BatchNorm divides by std(y), so a layer stored as
+# is loses 2^-9 (|mean|/std + 1) of the normalised signal; BatchNorm does not see a per-channel constant in front of
+# it (the conv bias cancels the same way, models/pointnet2_utils.py:149-151), so the GEMM epilogue subtracts one close
+# to the batch mean before rounding.  The constant is the PREVIOUS step's batch mean of the layer, kept in a plain
+# fp32 tensor on the BatchNorm module (`_pcb_centre`: not a registered buffer -- state_dict keys stay the reference's)
+# and moved by the layer's finalize kernel whenever the batch mean has drifted more than std/4 away from it; the first
+# training call of a layer runs its GEMM twice (probe: learn the mean, then store centred on it).  Eval mode centres on running_mean - bias exactly.
+# ---------------------------------------------------------------------------------------------
+CF_PROBE, CF_EVAL = 1, 2
+_centring = os.environ.get("PCB_CENTRE", "1") != "0"
+
+
+def set_centring(flag):
+    """Enable / disable centred storage of pre-BatchNorm rows in bf16 mode (A/B runs, tests).  Returns the previous setting."""
+    global _centring
+    old, _centring = _centring, bool(flag)
+    return old
+
+
+def _centre_args(bn, C, training, sync=False):
+    """(centre tensor or None, flags) for one layer of a bf16 stack call (desc slots [16], [17])."""
+    if not _centring:
+        return None, 0
+    if not training:
+        return None, CF_EVAL
+    dev = bn.weight.device if bn.weight is not None else (bn.running_mean.device if bn.running_mean is not None else None)
+    if dev is None or dev.type != "cuda":
+        return None, 0
+    c = getattr(bn, "_pcb_centre", None)
+    if c is None or c.device != dev or c.numel() != C:
+        if torch.cuda.is_current_stream_capturing():
+            return None, 0   # a buffer that outlives the capture cannot be created inside it: this call stays uncentred
+        c = torch.zeros(C, dtype=torch.float32, device=dev)
+        bn._pcb_centre = c
+        bn._pcb_centre_ok = False
+    flags = 0
+    if not getattr(bn, "_pcb_centre_ok", False):
+        # (under SyncBatchNorm the probe's statistics are all-reduced like any other: every rank learns the GLOBAL mean)
+        flags = CF_PROBE
+        bn._pcb_centre_ok = True
+    return c, flags
+
+
+def centre_state(module):
+    """{submodule name: centre tensor (a copy)} of every BatchNorm layer under `module` that holds an estimate.  The centres
+    are engine state like the running statistics but NOT part of state_dict() (the reference's keys are kept): two models
+    with equal parameters and equal centres produce equal bits; with different centres, equal values up to bf16 rounding."""
+    return {name: m._pcb_centre.clone() for name, m in module.named_modules()
+            if getattr(m, "_pcb_centre", None) is not None and getattr(m, "_pcb_centre_ok", False)}
+
+
+def load_centre_state(module, state):
+    """Install centres saved by centre_state() (layers without an entry forget theirs and probe again)."""
+    for name, m in module.named_modules():
+        if name in state:
+            m._pcb_centre = state[name].clone()
+            m._pcb_centre_ok = True
+        elif hasattr(m, "_pcb_centre"):
+            del m._pcb_centre
+            m._pcb_centre_ok = False
+
+
+def reset_centres(module):
+    """Forget every centre under `module` (the next training call of each layer probes again): what a caller does
+    beside reset_running_stats() / load_state_dict() when it wants a replay to reproduce an earlier run bit for bit."""
+    load_centre_state(module, {})
+
+
 _MAX_PARTS = 768     # slabs a gemm_nt launch writes at most (PCB_MAX_SLABS)
 _GATHER_PARTS = 1024  # a gathered first layer
 
@@ -409,12 +538,13 @@ class _FusedStack(torch.autograd.Function):
 
     Flat argument list: x, act, pool, perm, stat_repeat, L, mode, sync group (or False), then per layer
     (weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
-    num_batches_tracked or None -- incremented by the finalize kernel); optionally, behind the layers,
+    num_batches_tracked or None -- incremented by the finalize kernel --, centre or None, centre flags: see
+    _centre_args); optionally, behind the layers,
     (add1, add2 or None, sh1, sh2): fp32 rows [R >> sh, C_0] added to layer 0's product, each standing for 2^sh
     consecutive rows (conv_bn_act_levels; pcb_hip.h desc slot [15]).  Layer 0's weight may then be a column slice of
     a wider weight."""
 
-    NPER = 10
+    NPER = 12
     NHEAD = 8
 
     @staticmethod
@@ -655,10 +785,10 @@ class _GatheredStack(torch.autograd.Function):
     Backward returns du, dv, dwx; autograd takes du, dv on through the caller's point_linear calls.
 
     Flat argument list: u, v, wx, xyz, ctr, idx, ns, act, pool, L, then per layer (weight, bias,
-    gamma, beta, running_mean, running_var, training, momentum, eps, num_batches_tracked or None);
-    layer 0's weight is None."""
+    gamma, beta, running_mean, running_var, training, momentum, eps, num_batches_tracked or None, centre or None,
+    centre flags); layer 0's weight is None."""
 
-    NPER = 10
+    NPER = 12
     NHEAD = 10
 
     @staticmethod
@@ -763,15 +893,19 @@ class _GatheredStack(torch.autograd.Function):
         return (du, dv, None if dwx is None else dwx[0], None, None, None, None, None, None, None, *grads)
 
 
-def _layer_args(conv, bn, with_weight=True):
-    """(weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, counter) of one layer."""
+def _layer_args(conv, bn, with_weight=True, m=None, sync=False):
+    """(weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, counter, centre, centre flags)
+    of one layer; m: the row type of the call (centred storage is a bf16 matter)."""
     momentum = bn.momentum if bn.momentum is not None else _bn_bookkeeping(bn)
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     track = bn.track_running_stats and bn.running_mean is not None
+    centre, cflags = (None, 0)
+    if m is _MODES["bf16"]:
+        centre, cflags = _centre_args(bn, conv.out_channels, training, sync)
     return [conv.weight if with_weight else None, conv.bias, bn.weight, bn.bias,
             bn.running_mean if (track or not training) else None,
             bn.running_var if (track or not training) else None,
-            training, momentum, bn.eps, _counter(bn)]
+            training, momentum, bn.eps, _counter(bn), centre, cflags]
 
 
 def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0, wx=None, xyz=None, ctr=None):
@@ -785,7 +919,7 @@ def gathered_mlp(convs, bns, u, v, idx, act=ACT_RELU, pool=0, wx=None, xyz=None,
         raise ValueError("a gathered stack pools over its own neighbour axis")
     flat = []
     for i, (conv, bn) in enumerate(zip(convs, bns)):
-        flat += _layer_args(conv, bn, with_weight=bool(i))
+        flat += _layer_args(conv, bn, with_weight=bool(i), m=_MODES["bf16"])
     return _GatheredStack.apply(u.contiguous(), None if v is None else v.contiguous(),
                                 wx,
                                 None if wx is None else xyz.contiguous(), None if wx is None else ctr.contiguous(),
@@ -808,7 +942,7 @@ def gathered_ok(convs, bns):
 
 
 def _stack_desc(layers, widths, ybuf, R, m, outs=None, ext=None):
-    """Host descriptor table of pcb_mlp_stack_forward/backward: 16 int64 per layer (pcb_hip.h).  ext: layer 0's
+    """Host descriptor table of pcb_mlp_stack_forward/backward: 18 int64 per layer (pcb_hip.h).  ext: layer 0's
     slot [15] (a ctypes array of 7 int64 the caller keeps alive over the call) or None."""
     vals, yoff = [], 0
     ybase = ybuf.data_ptr()
@@ -829,7 +963,9 @@ def _stack_desc(layers, widths, ybuf, R, m, outs=None, ext=None):
                  0 if o[0] is None else o[0].data_ptr(), 0 if o[1] is None else o[1].data_ptr(),
                  0 if o[2] is None else o[2].data_ptr(), 0 if o[3] is None else o[3].data_ptr(),
                  t[9].data_ptr() if (len(t) > 9 and t[9] is not None) else 0,
-                 ctypes.addressof(ext) if (ext is not None and l == 0) else 0]
+                 ctypes.addressof(ext) if (ext is not None and l == 0) else 0,
+                 t[10].data_ptr() if (len(t) > 10 and t[10] is not None) else 0,
+                 int(t[11]) if len(t) > 11 else 0]
         yoff += R * C
     return (ctypes.c_longlong * len(vals))(*vals)
 
@@ -848,7 +984,7 @@ def _fused_stack(convs, bns, x, act, pool, perm, stat_repeat=1):
     # num_batches_tracked += 1 (nn.BatchNorm.forward does it per module) rides along in the layer's
     # finalize kernel; the count itself is only read on the host when momentum=None
     for conv, bn in zip(convs, bns):
-        flat += _layer_args(conv, bn)
+        flat += _layer_args(conv, bn, m=m, sync=use_sync)
     return _FusedStack.apply(xr, act, pool, perm, stat_repeat, len(convs), m, group if use_sync else False, *flat)
 
 
@@ -1292,7 +1428,7 @@ def conv_bn_act_levels(conv, bn, levels, reps, act=ACT_RELU, concat=None):
     shs = [reps[i].bit_length() - 1 for i in coarse]
     shs += [shs[-1]] * (2 - len(shs))
     use_sync, group = _sync_group([bn])
-    flat = _layer_args(conv, bn)
+    flat = _layer_args(conv, bn, m=m, sync=use_sync)
     flat[0] = pieces[full[0]]
     xr = x if (x.dtype == m.dtype and x.is_contiguous()) else x.to(m.dtype).contiguous()
     return _FusedStack.apply(xr, act, 0, 0, 1, 1, m, group if use_sync else False, *flat, adds[0], adds[1], shs[0], shs[1])

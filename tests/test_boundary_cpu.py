@@ -54,11 +54,11 @@ def test_argument_validation_without_gpu(lib):
 
 
 def _desc(widths, Kp, gathered=False):
-    """Host descriptor of pcb_mlp_stack_* (16 int64 per layer) with dummy non-null pointers."""
+    """Host descriptor of pcb_mlp_stack_* (PCB_STACK_DESC_SLOTS = 18 int64 per layer) with dummy non-null pointers."""
     vals, kp = [], Kp
     for l, C in enumerate(widths):
         w = 0 if (gathered and l == 0) else 64
-        vals += [w, 0, 0, 0, 0, 0, C, 0 if w == 0 else kp, 1, 64, 0, 0, 0, 0, 0, 0]
+        vals += [w, 0, 0, 0, 0, 0, C, 0 if w == 0 else kp, 1, 64, 0, 0, 0, 0, 0, 0, 0, 0]
         kp = C
     return (ctypes.c_longlong * len(vals))(*vals)
 

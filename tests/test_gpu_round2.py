@@ -79,23 +79,28 @@ def test_training_steps_follow_the_reference_loop():
     assert rel_err(final, g["final_logits_eval"]) < 5e-2
 
 
-# Measured on MI355X (tools/bf16_parity.py, round 2): bf16 rows against the REFERENCE's fp32 outputs
+# Measured on MI355X (tools/bf16_parity.py, round 3: rows stored centred): bf16 rows against the REFERENCE's fp32 outputs
 # (relative: max |d| / max |ref| and mean |d| / mean |ref| for logits).
 #   name            eval max / mean       train max / mean      loss      grad norms median / max
-#   pn2_ssg         4.8e-3 / 1.6e-3       1.48e-1 / 1.64e-1     1.1e-3    2.1e-2 / 0.25
-#   pn2_ssg_skip    4.7e-3 / 2.0e-3       1.08e-1 / 1.46e-1     1.5e-4    1.6e-2 / 0.20
-#   pn2_msg         5.6e-3 / 2.0e-3       1.53e-1 / 1.34e-1     8.7e-4    2.1e-2 / 0.31
-# Eval mode is bf16 rounding noise (2^-9 per stored activation).  Train mode is ~50x worse, and
-# tools/bf16_stage_err.py shows why: the error grows layer by layer (sa1 0.8 % ... fp1 11 %) because a
-# stored pre-BatchNorm value y carries an absolute error of 2^-9 |y| while BatchNorm with BATCH
-# statistics divides by std(y): the error in units of the normalised signal is 2^-9 (|mean|/std + 1)
-# per layer, and |mean|/std is 1.5-9 over these layers (in eval mode the running variance of a fresh
-# network is ~1, so nothing is amplified).  The loss and the gradient norms stay close because the
-# error is a smooth per-point perturbation.  Bars = about twice the measured values.
+#   pn2_ssg         4.7e-3 / 1.6e-3       1.55e-1 / 1.43e-1     4.9e-4    1.3e-2 / 0.17      (round 2: 1.48e-1 / 1.64e-1, 2.1e-2 / 0.25)
+#   pn2_ssg_skip    5.2e-3 / 2.0e-3       9.0e-2  / 1.27e-1     2.6e-4    1.7e-2 / 0.21      (         1.08e-1 / 1.46e-1, 1.6e-2 / 0.20)
+#   pn2_msg         5.9e-3 / 1.9e-3       1.58e-1 / 1.12e-1     5.0e-4    2.1e-2 / 0.21      (         1.53e-1 / 1.34e-1, 2.1e-2 / 0.31)
+# Eval mode is bf16 rounding noise (2^-9 per stored activation).  Train mode is ~50x worse, and round 2 blamed the wrong
+# thing (2^-9 |y| divided by std(y), i.e. the |mean|/std of the stored rows): centred storage removes exactly that factor
+# and buys 15 % of the mean error.  What tools/bf16_mixed.py measures instead: a freshly initialised ReLU + BatchNorm
+# network AMPLIFIES independent noise relative to its signal, ~1.2x per layer -- a ReLU halves the variance of the
+# noise but turns two thirds of the signal's variance into a mean that the next train-mode BatchNorm removes (eval-mode
+# BatchNorm of a fresh network removes nothing, hence the 50x).  ONE perturbation of relative size 2^-9 behind sa1 of the
+# fp32 engine arrives at the logits as 3.0e-2 (max) / 2.1e-2 (mean); behind sa2 1.8e-2, sa3 5.6e-3, fp1 1.2e-3.  With ~9
+# roundings per stage the bf16 engine cannot be closer than ~1e-1 to fp32 train-mode logits of THIS network at
+# initialisation whatever it stores (fp32 rows up to and including sa1: 5e-2; sa1+sa2: 2.5e-2; the whole encoder:
+# 2.0e-2) -- and the fp32 engine's own 6e-6 is the same amplification applied to 2^-24.  The loss and the gradient norms
+# stay close because the error is a smooth per-point perturbation.  rowmlp.bind_precision(model.sa1, "fp32") is the knob
+# for a caller who wants the first stages exact.  Bars = about twice the measured values.
 _BF16_BARS = {
-    "model_pn2_ssg": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=5e-2, gn_max=0.6),
-    "model_pn2_ssg_skip": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=5e-2, gn_max=0.6),
-    "model_pn2_msg": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=5e-2, gn_max=0.6),
+    "model_pn2_ssg": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=4.5e-2, gn_max=0.45),
+    "model_pn2_ssg_skip": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=4.5e-2, gn_max=0.45),
+    "model_pn2_msg": dict(eval_max=1.2e-2, eval_mean=5e-3, train_max=0.3, train_mean=0.3, loss=3e-3, gn_median=4.5e-2, gn_max=0.45),
 }
 
 
@@ -415,6 +420,7 @@ def test_branch_streams_change_nothing():
         def step(flag):
             pu.set_branch_streams(flag)
             model.load_state_dict(state)
+            rowmlp.reset_centres(model)
             torch.manual_seed(7)  # FPS start indices
             bucket.zero()
             loss = bench.loss_fn(model(xyz, colors), labels, cdim)

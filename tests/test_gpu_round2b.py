@@ -215,6 +215,7 @@ def test_prepare_step_changes_nothing_but_the_launch_count(precision):
         assert float((la - lb).abs().max() / lb.abs().max()) < (3e-2 if precision == "fp32" else 2.5e-1)
         # same weights in both: a forward pass on prepared operands IS the forward pass on self-prepared ones
         b.load_state_dict(a.state_dict())
+        rowmlp.load_centre_state(b, rowmlp.centre_state(a))   # engine state beside the state_dict (bf16 rows)
         a.train(), b.train()
         rowmlp.prepare_step()
         hits = rowmlp._step_stats[0]
@@ -228,6 +229,7 @@ def test_prepare_step_changes_nothing_but_the_launch_count(precision):
         # a weight edited after prepare_step(): the stale operands must not be used
         rowmlp.set_step_operands(True)
         b.load_state_dict(a.state_dict())   # (running statistics moved in the forward passes above)
+        rowmlp.load_centre_state(b, rowmlp.centre_state(a))
         rowmlp.prepare_step()
         with torch.no_grad():
             for net in (a, b):
@@ -344,7 +346,7 @@ def test_gemm_with_repeated_addends_and_their_gradient_sums(two):
     nparts = 19
     sums = torch.full((nparts, 2, N), float("nan"), device="cuda")
     assert L.pcb_gemm_nt_stats_add_bf16(a.data_ptr(), w.data_ptr(), R, N, K, out.data_ptr(), sums.data_ptr(), nparts,
-                                        add1.data_ptr(), sh1, 0 if add2 is None else add2.data_ptr(), sh2, _stream()) == 0
+                                        add1.data_ptr(), sh1, 0 if add2 is None else add2.data_ptr(), sh2, 0, _stream()) == 0
     ref = a.float() @ w.float().t() + add1.repeat_interleave(1 << sh1, dim=0)
     if two:
         ref = ref + add2.repeat_interleave(1 << sh2, dim=0)
@@ -352,9 +354,19 @@ def test_gemm_with_repeated_addends_and_their_gradient_sums(two):
     tot = sums.double().sum(0)
     assert torch.allclose(tot[0], out.double().sum(0), rtol=1e-5, atol=1e-3)
     assert torch.allclose(tot[1], (out.double() ** 2).sum(0), rtol=1e-5, atol=1e-3)
+    # rows stored centred: out = bf16(product + addends - centre), statistics of those rows
+    centre = torch.randn(N, device="cuda") * 3
+    assert L.pcb_gemm_nt_stats_add_bf16(a.data_ptr(), w.data_ptr(), R, N, K, out.data_ptr(), sums.data_ptr(), nparts,
+                                        add1.data_ptr(), sh1, 0 if add2 is None else add2.data_ptr(), sh2,
+                                        centre.data_ptr(), _stream()) == 0
+    refc = ref - centre
+    assert (out.float() - refc).abs().max() <= 2e-2 * refc.abs().max()
+    tot = sums.double().sum(0)
+    assert torch.allclose(tot[0], out.double().sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(tot[1], (out.double() ** 2).sum(0), rtol=1e-5, atol=1e-3)
     # shifts below 2 are refused (the epilogue takes one coarse row per run of 4 output rows)
     assert L.pcb_gemm_nt_stats_add_bf16(a.data_ptr(), w.data_ptr(), R, N, K, out.data_ptr(), sums.data_ptr(), nparts,
-                                        add1.data_ptr(), 1, 0, 1, _stream()) < 0
+                                        add1.data_ptr(), 1, 0, 1, 0, _stream()) < 0
 
     C = N
     dz = torch.randn(R, C, device="cuda").to(torch.bfloat16)
