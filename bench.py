@@ -163,6 +163,7 @@ class Run:
                 if isinstance(m, torch.nn.Dropout):
                     m.p = 0.0
         self.model = model
+        rowmlp.attach_step_operands(model)   # this run's own operand set: a captured step bakes in ITS tables and buffers only
         self.use_graph = mode == "train" and graph
         # inference through one captured hipGraph per batch (pn2_msg / pn2_ssg: the eager eval pass is bound by the
         # host -- ~160 launches, 2.4-2.8 ms of enqueueing against 2.6 ms of GPU time)
@@ -226,7 +227,7 @@ class Run:
         if self.args.dump and self.i == 0:
             self.first_grad = flat.detach().clone()  # the averaged gradient of the first step (equivalence tests)
         self.opt.step(flat)
-        self.rowmlp.prepare_step()   # the operands of every stack from the new weights: one launch (rowmlp.prepare_step)
+        self.rowmlp.prepare_step(self.model)   # the operands of every stack from the new weights: one launch (rowmlp.prepare_step)
         self.i += 1
         return loss
 
@@ -317,7 +318,7 @@ class Run:
         loss_buf = torch.zeros((), device=self.device)
 
         def fwd_bwd():
-            self.rowmlp.prepare_step()           # operands of every stack from the weights the last Adam step left
+            self.rowmlp.prepare_step(model)      # operands of every stack from the weights the last Adam step left
             if static is not None:
                 static.commit()                  # what the previous step computed for this batch becomes live
             loss = self.loss_of(model(xyz, colors), batch)
@@ -616,7 +617,7 @@ def main():
             iso_other = other.isolated_launches()
         if other is not None:
             other.close()
-            del other
+        other = eager = graph = None   # really released: nothing of the dropped run outlives this point (its operand set is its own)
         if run.use_graph:
             pu.set_static_sampling(run.static)        # (only the eager steps of the captured run read it)
         pu.set_scene_shard(rank if strong else 0, world if strong else 1)

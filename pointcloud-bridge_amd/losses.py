@@ -9,6 +9,8 @@ class pair, ~20 per step); here the same conditions multiply the additions as 0/
 criterion enqueues without reading anything back.  Plain torch ops on [B,N] masks -- no kernel of its
 own; runs wherever its inputs live.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -117,14 +119,28 @@ def _as_rows(logits, channels_last):
     return x if x.stride(0) >= C else None
 
 
-def cross_entropy(logits, labels, channels_last=False, ignore_index=-100):
+_CHECK_LABELS = os.environ.get("PCB_CHECK_LABELS", "0") != "0"
+
+
+def cross_entropy(logits, labels, channels_last=False, ignore_index=-100, check_labels=None):
     """nn.CrossEntropyLoss()(logits, labels) as the reference's trainers call it -- logits [B,C,N] (or
     [B,N,C] / [R,C] with channels_last), labels [B,N] / [R] int64 -- on the library's one-pass kernel when the
-    logits are GPU fp32 rows in memory; any other input (CPU tensors, other layouts or dtypes) goes to
-    F.cross_entropy, the reference's own call."""
+    logits are GPU fp32 rows in memory AND the labels live on the same GPU; any other input (CPU tensors or labels,
+    labels on another device, other layouts or dtypes) goes to F.cross_entropy, the reference's own call, which
+    raises its usual errors for mismatched devices.
+
+    Labels outside [0, C) that are not ignore_index: F.cross_entropy trips a device-side assertion; the kernel
+    (csrc/loss.hip) never dereferences them and counts such points as ignored -- bad label data would train
+    silently.  check_labels=True (default: the environment variable PCB_CHECK_LABELS, off) validates the range first
+    and raises IndexError; it costs a host synchronisation per call, so it is a debugging switch."""
     rows = _as_rows(logits, channels_last)
-    if rows is None or labels.dtype != torch.int64 or labels.numel() != rows.shape[0]:
+    same_gpu = labels.is_cuda and labels.device == logits.device
+    if rows is None or not same_gpu or labels.dtype != torch.int64 or labels.numel() != rows.shape[0]:
         if channels_last and logits.dim() == 3:
             return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=ignore_index)
         return F.cross_entropy(logits, labels, ignore_index=ignore_index)
+    if _CHECK_LABELS if check_labels is None else check_labels:
+        bad = (labels != ignore_index) & ((labels < 0) | (labels >= rows.shape[1]))
+        if bool(bad.any()):
+            raise IndexError(f"cross_entropy: {int(bad.sum())} labels outside [0, {rows.shape[1]}) and != ignore_index")
     return _CrossEntropyRows.apply(rows, labels.reshape(-1).contiguous(), ignore_index)

@@ -260,15 +260,16 @@ def note_parameter_update(weights=True):
 # prepared and tell the library to skip the launch (need_wt0 bit 2).  A stack registers itself the
 # first time it runs; an entry is valid for exactly the parameter tensors (storage addresses, version
 # counters, weight generation) it was prepared from -- anything else falls back to the per-stack launch.
+#
+# OWNERSHIP (round 3).  The registry is an object, StepOperands: one per model that asks for one
+# (attach_step_operands(model): the model's forward pass registers its stacks there, prepare_step(model) fills them),
+# plus a process default for callers that never attach.  So a captured hipGraph of model A bakes in the table and the
+# buffers of A's OWN set: registering, training or dropping model B cannot touch them.  Inside a set nothing that a
+# launch may have seen is ever freed: a table or an operand buffer that is replaced (a new stack registered, a
+# parameter moved to other storage) is RETIRED -- kept alive by the set -- because a captured graph may still hold its
+# address.  Tables are kept per (device, row type).
 # ---------------------------------------------------------------------------------------------
 _weights_generation = 0
-_step_entries = {}
-_step_table = None        # (device int64 tensor, rows, max elements, mode code) per mode code, or None when stale
-_step_prepared = (-1, -1)  # (_step_serial, _weights_generation) of the last prepare_step
-_step_serial = 0
-_step_stats = [0, 0]   # stack calls that found their operands prepared / that prepared them themselves
-
-
 _step_enabled = True
 
 
@@ -307,75 +308,134 @@ def _step_rows(weights, Kp, perm, need_wt0, q):
     return rows, off
 
 
+class StepOperands:
+    """The persistent GEMM operands of a set of stacks (normally: one model's) and the device tables one launch per
+    optimiser step fills them from.  See the section comment above for ownership and lifetime."""
+
+    def __init__(self):
+        self.entries = {}
+        self.tables = None        # {(device, mode code): (int64 table tensor, rows, workgroups)} or None when stale
+        self.prepared = (-1, -1)  # (serial, _weights_generation) of the last prepare()
+        self.serial = 0
+        self.stats = [0, 0]       # stack calls that found their operands prepared / that prepared them themselves
+        self.retired = []         # replaced tables / operand buffers: a captured graph may still hold their addresses
+
+    def lookup(self, kind, weights, Kp, perm, need_wt0, m, nelem, dev):
+        """(wbuf, flag) for a training-mode stack call: the entry's persistent operand buffer and 4 if the last
+        prepare() filled it from exactly these parameters, else 0 (the call prepares them itself)."""
+        first = next(w for w in weights if w is not None)
+        key = (kind, id(first), Kp, perm, len(weights), m.code, int(need_wt0))
+        ptrs = tuple(0 if w is None else w.data_ptr() for w in weights)
+        e = self.entries.get(key)
+        if e is None or e.ptrs != ptrs or not e.alive() or e.wbuf.numel() != max(nelem, 1) or e.wbuf.device != dev:
+            if e is not None:
+                self.retired.append(e.wbuf)
+            e = _StepEntry()
+            e.refs = [weakref.ref(w) for w in weights if w is not None]
+            e.ptrs = ptrs
+            e.rows, _ = _step_rows(weights, Kp, perm, need_wt0, m.q)
+            e.wbuf = torch.empty(max(nelem, 1), dtype=m.dtype, device=dev)
+            e.serial = -1
+            e.versions = None
+            e.code = m.code
+            self.entries[key] = e
+            self._retire_tables()
+            return e.wbuf, 0
+        if (e.serial == self.prepared[0] and self.prepared[1] == _weights_generation
+                and e.versions == tuple(w._version for w in weights if w is not None)):
+            self.stats[0] += 1
+            return e.wbuf, 4
+        self.stats[1] += 1
+        return e.wbuf, 0
+
+    def _retire_tables(self):
+        if self.tables is not None:
+            self.retired.extend(t for t, _, _ in self.tables.values())
+            self.tables = None
+
+    def prepare(self):
+        """One launch per (device, row type): the operands of every registered stack from the current weights."""
+        dead = [k for k, e in self.entries.items() if not e.alive()]
+        for k in dead:
+            self.retired.append(self.entries.pop(k).wbuf)
+            self._retire_tables()
+        if not self.entries:
+            return
+        if self.tables is None:
+            rows = {}
+            for e in self.entries.values():
+                live = [r() for r in e.refs]
+                base, es = e.wbuf.data_ptr(), e.wbuf.element_size()
+                it = iter(live)
+                vals, most = rows.setdefault((e.wbuf.device, e.code), ([], [0]))   # most[0]: workgroups so far (one 32 x 32 tile each)
+                for (l, C, k, kp, perm, wp, wt) in e.rows:
+                    w = next(it)
+                    vals += [w.data_ptr(), base + es * wp, 0 if wt < 0 else base + es * wt, C, k, kp, perm, most[0]]
+                    most[0] += ((C + 31) // 32) * ((kp + 31) // 32)
+            self.tables = {key: (torch.tensor(vals, dtype=torch.int64, device=key[0]), len(vals) // 8, most[0])
+                           for key, (vals, most) in rows.items()}
+        self.serial += 1
+        for (dev, code), (table, n, most) in self.tables.items():
+            sfx = "bf16" if code == _MODES["bf16"].code else "f32"
+            with on_device(dev):
+                _launch("pcb_prep_weights_table_" + sfx, n, table.data_ptr(), n, most)
+        for e in self.entries.values():
+            e.serial = self.serial
+            e.versions = tuple(r()._version for r in e.refs)
+        self.prepared = (self.serial, _weights_generation)
+
+
+_default_operands = StepOperands()
+_step_stats = _default_operands.stats   # (tests read the default set's counters)
+
+
+def _current_operands():
+    stack = getattr(_tls, "opsets", None)
+    return stack[-1] if stack else _default_operands
+
+
+def attach_step_operands(module):
+    """Give `module` (a whole network) its OWN StepOperands: stacks that run inside its forward pass register there,
+    prepare_step(module) fills them.  Returns the set (idempotent)."""
+    ops = getattr(module, "_pcb_step_operands", None)
+    if ops is not None:
+        return ops
+    ops = module._pcb_step_operands = StepOperands()
+
+    def enter(mod, args):
+        stack = getattr(_tls, "opsets", None)
+        if stack is None:
+            stack = _tls.opsets = []
+        stack.append(mod._pcb_step_operands)
+
+    def leave(mod, args, out):
+        _tls.opsets.pop()
+
+    module.register_forward_pre_hook(enter)
+    module.register_forward_hook(leave, always_call=True)
+    return ops
+
+
 def _step_operands(kind, weights, Kp, perm, need_wt0, m, nelem, dev):
-    """(wbuf, flag) for a training-mode stack call: the entry's persistent operand buffer and 4 if the last
-    prepare_step filled it from exactly these parameters, else 0 (the call prepares them itself)."""
-    global _step_table
     if not _step_enabled:
         return torch.empty(max(nelem, 1), dtype=m.dtype, device=dev), 0
-    first = next(w for w in weights if w is not None)
-    key = (kind, id(first), Kp, perm, len(weights), m.code, int(need_wt0))
-    ptrs = tuple(0 if w is None else w.data_ptr() for w in weights)
-    e = _step_entries.get(key)
-    if e is None or e.ptrs != ptrs or not e.alive() or e.wbuf.numel() != max(nelem, 1) or e.wbuf.device != dev:
-        e = _StepEntry()
-        e.refs = [weakref.ref(w) for w in weights if w is not None]
-        e.ptrs = ptrs
-        e.rows, _ = _step_rows(weights, Kp, perm, need_wt0, m.q)
-        e.wbuf = torch.empty(max(nelem, 1), dtype=m.dtype, device=dev)
-        e.serial = -1
-        e.versions = None
-        e.code = m.code
-        if len(_step_entries) > 4096:
-            _step_entries.clear()
-        _step_entries[key] = e
-        _step_table = None
-        return e.wbuf, 0
-    if (e.serial == _step_prepared[0] and _step_prepared[1] == _weights_generation
-            and e.versions == tuple(w._version for w in weights if w is not None)):
-        _step_stats[0] += 1
-        return e.wbuf, 4
-    _step_stats[1] += 1
-    return e.wbuf, 0
+    return _current_operands().lookup(kind, weights, Kp, perm, need_wt0, m, nelem, dev)
 
 
-def prepare_step():
+def prepare_step(module=None):
     """Call after every optimiser step (the trainer and bench.py do): prepares the operands of all registered
-    stacks from the current weights with one launch per row type.  Purely an optimisation: stacks whose entry is
+    stacks -- of `module`'s own set (attach_step_operands) or, without an argument, of the process default set --
+    from the current weights with one launch per row type.  Purely an optimisation: stacks whose entry is
     not (or no longer) valid prepare their own operands as before.  An entry is trusted until a version counter
     of its weights moves or note_parameter_update() is called: code that edits weights through `.data` between
     this call and the forward pass must call one of the two (parallel.FlatAdam does)."""
-    global _step_table, _step_prepared, _step_serial
-    dead = [k for k, e in _step_entries.items() if not e.alive()]
-    for k in dead:
-        del _step_entries[k]
-        _step_table = None
-    if not _step_entries:
-        return
-    if _step_table is None:
-        tables = {}
-        for e in _step_entries.values():
-            live = [r() for r in e.refs]
-            base, es = e.wbuf.data_ptr(), e.wbuf.element_size()
-            it = iter(live)
-            vals, most = tables.setdefault(e.code, ([], [0]))   # most[0]: workgroups so far (one 32 x 32 tile each)
-            for (l, C, k, kp, perm, wp, wt) in e.rows:
-                w = next(it)
-                vals += [w.data_ptr(), base + es * wp, 0 if wt < 0 else base + es * wt, C, k, kp, perm, most[0]]
-                most[0] += ((C + 31) // 32) * ((kp + 31) // 32)
-        dev = next(iter(_step_entries.values())).wbuf.device
-        _step_table = {code: (torch.tensor(vals, dtype=torch.int64, device=dev), len(vals) // 8, most[0])
-                       for code, (vals, most) in tables.items()}
-    _step_serial += 1
-    dev = next(iter(_step_entries.values())).wbuf.device
-    with on_device(dev):
-        for code, (table, n, most) in _step_table.items():
-            sfx = "bf16" if code == _MODES["bf16"].code else "f32"
-            _launch("pcb_prep_weights_table_" + sfx, n, table.data_ptr(), n, most)
-    for e in _step_entries.values():
-        e.serial = _step_serial
-        e.versions = tuple(r()._version for r in e.refs)
-    _step_prepared = (_step_serial, _weights_generation)
+    ops = _default_operands if module is None else getattr(module, "_pcb_step_operands", None)
+    if ops is None:
+        raise ValueError("prepare_step(module): call attach_step_operands(module) first")
+    ops.prepare()
+
+
+_eval_retired = []   # buffers of replaced / evicted cache entries that a captured graph has seen (see _eval_store)
 
 
 def _eval_lookup(layers, first, extra):
@@ -384,14 +444,32 @@ def _eval_lookup(layers, first, extra):
     key = (id(first), _centring) + extra
     hit = _eval_operands.get(key)
     if hit is not None and hit[0]() is first and hit[1] == versions:
+        if not hit[3][0] and torch.cuda.is_current_stream_capturing():
+            hit[3][0] = True   # a hipGraph now holds these addresses
         return key, versions, hit[2]
     return key, versions, None
 
 
 def _eval_store(key, first, versions, bufs):
+    """Keep the prepared operands of an eval-mode call.  An entry that is replaced (the parameters moved on) or evicted
+    is simply dropped -- unless a captured graph has used its buffers: such a graph is stale in its VALUES once the
+    weights change (inference with constant weights is what it captured), but its replay must not walk freed memory,
+    so those buffers are retired instead."""
+    def drop(entry):
+        if entry[3][0]:
+            _eval_retired.append(entry[2])
+
     if len(_eval_operands) > 4096:
-        _eval_operands.clear()
-    _eval_operands[key] = (weakref.ref(first), versions, bufs)
+        for k in [k for k, e in _eval_operands.items() if e[0]() is None]:
+            drop(_eval_operands.pop(k))
+        if len(_eval_operands) > 4096:
+            for e in _eval_operands.values():
+                drop(e)
+            _eval_operands.clear()
+    old = _eval_operands.get(key)
+    if old is not None:
+        drop(old)
+    _eval_operands[key] = (weakref.ref(first), versions, bufs, [torch.cuda.is_current_stream_capturing()])
 
 
 # ---------------------------------------------------------------------------------------------

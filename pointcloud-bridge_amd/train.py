@@ -84,6 +84,7 @@ class Trainer:
         called as criterion(logits, labels, points) like losses.BridgeStructureLoss
         (train_MulSca_BriStruNet_CB.py:151-156, :178)."""
         self.model = model
+        rowmlp.attach_step_operands(model)   # the model's own operand set (rowmlp.StepOperands)
         self.criterion = criterion
         self.num_classes = num_classes
         self.channels_last = type(model).__name__ == "DGCNN"  # DGCNN returns [B,N,C] (DGCNN.py:170)
@@ -106,7 +107,7 @@ class Trainer:
         if self.bucket is not None:
             self.bucket.reduce()
         self.opt.step()
-        rowmlp.prepare_step()   # GEMM operands of every stack from the updated weights, one launch
+        rowmlp.prepare_step(self.model)   # GEMM operands of every stack from the updated weights, one launch
         return loss.detach()
 
     @torch.no_grad()

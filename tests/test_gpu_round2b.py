@@ -59,6 +59,28 @@ def test_cross_entropy_strided_rows_and_fallback():
     assert abs(float(cpu) - float(ref)) <= 1e-5 * abs(float(ref))
 
 
+def test_cross_entropy_labels_elsewhere_and_out_of_range():
+    """labels that do not live on the logits' GPU never reach the kernel (their raw address would be read by
+    the GPU): the call goes to F.cross_entropy and fails the way the reference's call does -- a RuntimeError, no fault.
+    Labels outside [0, C): counted as ignored by the kernel (documented); check_labels=True raises IndexError."""
+    from pointcloud_bridge_amd.losses import cross_entropy
+    torch.manual_seed(6)
+    rows = torch.randn(2048, 5, device="cuda", requires_grad=True)
+    labels = torch.randint(0, 5, (2048,), device="cuda")
+    with pytest.raises(RuntimeError):
+        cross_entropy(rows, labels.cpu(), channels_last=True)
+    ok = cross_entropy(rows, labels, channels_last=True, check_labels=True)
+    assert abs(float(ok) - float(F.cross_entropy(rows, labels))) <= 2e-6 * abs(float(ok))
+    bad = labels.clone()
+    bad[:7] = 9
+    with pytest.raises(IndexError):
+        cross_entropy(rows, bad, channels_last=True, check_labels=True)
+    # unchecked: the 7 points are skipped exactly like ignore_index points
+    skipped = labels.clone()
+    skipped[:7] = -100
+    assert float(cross_entropy(rows, bad, channels_last=True)) == float(cross_entropy(rows, skipped, channels_last=True))
+
+
 @pytest.mark.parametrize("sfx,dtype", [("bf16", torch.bfloat16), ("f32", torch.float32)])
 @pytest.mark.parametrize("R,C", [(50000, 128), (8192, 1536), (333, 64)])
 def test_bwd_reduce_slabs(sfx, dtype, R, C):
