@@ -213,10 +213,17 @@ class StaticSampling:
         self.propagation = list(propagation or ())
         self.extra = {}   # key -> (live tensors, staging tensors), allocated at the first compute()
         n_in = N
-        for s in npoints:
-            lv = {"n_in": n_in, "npoint": int(s),
-                  "pinned": torch.zeros(B, dtype=torch.long).pin_memory(),
-                  "start": torch.zeros(B, dtype=torch.long, device=dev)}
+        # FPS start indices of all levels: ONE device buffer, filled by one asynchronous copy per draw() from a ring of
+        # pinned host buffers.  The host runs ahead of the GPU (a replay is enqueued in ~4 ms, executes in ~7): a single
+        # pinned buffer would be rewritten by the next draw() before the previous copy has executed, and a step would
+        # sample from its successor's start indices -- every slot carries an event recorded behind its copy
+        # and is only rewritten once that event has completed.
+        self._start_all = torch.zeros(len(npoints), B, dtype=torch.long, device=dev)
+        self._pinned = [torch.zeros(len(npoints), B, dtype=torch.long).pin_memory() for _ in range(4)]
+        self._pin_events = [None] * len(self._pinned)
+        self._pin_next = 0
+        for l, s in enumerate(npoints):
+            lv = {"n_in": n_in, "npoint": int(s), "start": self._start_all[l]}
             for tag in ("", "_s"):
                 lv["idx" + tag] = torch.zeros(B, int(s), dtype=torch.long, device=dev)
                 lv["new_xyz" + tag] = torch.zeros(B, int(s), 3, dtype=torch.float32, device=dev)
@@ -226,11 +233,19 @@ class StaticSampling:
     def draw(self):
         """Host side, outside any capture: one torch.randint per level from the CPU generator
         (reference :69), staged through pinned memory into the static start buffers."""
-        for lv in self.levels:
-            B = lv["start"].shape[0]
-            rank, world = _scene_shard
-            lv["pinned"].copy_(torch.randint(0, lv["n_in"], (B * world,), dtype=torch.long)[rank * B:(rank + 1) * B])
-            lv["start"].copy_(lv["pinned"], non_blocking=True)
+        i = self._pin_next
+        self._pin_next = (i + 1) % len(self._pinned)
+        if self._pin_events[i] is None:
+            self._pin_events[i] = torch.cuda.Event()
+        else:
+            self._pin_events[i].synchronize()   # the copy that last read this slot has executed (normally long ago)
+        host = self._pinned[i]
+        rank, world = _scene_shard
+        for l, lv in enumerate(self.levels):
+            B = host.shape[1]
+            host[l].copy_(torch.randint(0, lv["n_in"], (B * world,), dtype=torch.long)[rank * B:(rank + 1) * B])
+        self._start_all.copy_(host, non_blocking=True)
+        self._pin_events[i].record()
 
     def _stage(self, key, res):
         held = self.extra.get(key)

@@ -138,7 +138,13 @@ class OverlappedGradAllReduce:
     on its own stream: the encoder's gradients are still being computed while the decoder's travel).
     finish() waits for the collectives and returns the averaged flat gradient, laid out exactly like
     parallel.FlatAdam's parameter buffer.  A parameter that received no gradient in a step counts as
-    zero (every rank then reduces the same layout).  With one rank the hooks only do the packing."""
+    zero (every rank then reduces the same layout).  With one rank the hooks only do the packing.
+
+    ORDER.  Collectives must be issued in the same order on every rank.  A bucket is PACKED whenever its last gradient
+    lands, but its all-reduce is only SENT once every bucket behind it in parameter order has been sent -- the backward
+    pass walks the modules last to first, so that is the order buckets complete in anyway -- and finish() flushes what
+    is left in the same order.  A rank on which a branch received no gradient (its bucket completes only in finish())
+    therefore delays its own sends, it does not reorder them against its peers' (ADVICE r2)."""
 
     def __init__(self, params, buckets=None, group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -174,7 +180,11 @@ class OverlappedGradAllReduce:
             raise ValueError("every parameter must belong to a bucket")
         self.pending = [n for _, _, n in self.ranges]
         self.landed = [False] * len(self.params)
+        self.packed = [False] * len(self.ranges)
+        self.unsent = len(self.ranges)   # buckets [unsent, ...) have been sent; the next one to go is unsent - 1
+        self.sent_order = []             # (tests) bucket numbers in the order their collectives were issued
         self.works = []
+        self.pack_events = {}
         self.handles = [p.register_post_accumulate_grad_hook(self._hook(i)) for i, p in enumerate(self.params)]
 
     @classmethod
@@ -218,8 +228,26 @@ class OverlappedGradAllReduce:
                    for i in members], out=self.flat[lo:hi])
         for i in members:
             self.params[i].grad = None  # the flat buffer is the gradient from here on
-        if self.coll:
-            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.packed[b] = True
+        while self.unsent > 0 and self.packed[self.unsent - 1]:
+            self.unsent -= 1
+            k = self.unsent
+            self.sent_order.append(k)
+            if self.coll:
+                klo, khi, _ = self.ranges[k]
+                if self.flat.is_cuda and k != b:
+                    # packed earlier, by another node's hook, possibly on another stream: the collective (issued from
+                    # the current stream) must see that packing
+                    torch.cuda.current_stream().wait_event(self.pack_events[k])
+                self.works.append(dist.all_reduce(self.flat[klo:khi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.coll and self.flat.is_cuda and not self.packed_sent(b):
+            ev = self.pack_events.get(b)
+            if ev is None:
+                ev = self.pack_events[b] = torch.cuda.Event()
+            ev.record()
+
+    def packed_sent(self, b):
+        return b >= self.unsent
 
     def zero(self):
         """Call before every backward pass."""
@@ -227,12 +255,15 @@ class OverlappedGradAllReduce:
             p.grad = None
         self.pending = [n for _, _, n in self.ranges]
         self.landed = [False] * len(self.params)
+        self.packed = [False] * len(self.ranges)
+        self.unsent = len(self.ranges)
+        self.sent_order = []
         self.works = []
 
     def finish(self):
         """After backward: reduce what has not been reduced yet, wait, average.  Returns the flat gradient."""
-        for i, ok in enumerate(self.landed):
-            if not ok:  # no gradient this step: counts as zeros, so that every rank reduces the same layout
+        for i in reversed(range(len(self.landed))):   # (last bucket first: the order they are sent in)
+            if not self.landed[i]:  # no gradient this step: counts as zeros, so that every rank reduces the same layout
                 self.landed[i] = True
                 b = self.bucket_of[i]
                 self.pending[b] -= 1

@@ -30,3 +30,14 @@ def knn_tie_tolerant_mismatch(idx_a, idx_b, dist_of, rtol=0.0, atol=0.0):
             if not np.allclose(da, dc, rtol=rtol, atol=atol):
                 bad += 1
     return bad
+
+
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (bind to port 0): two suites on one box must not meet on a fixed
+    rendezvous port."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p

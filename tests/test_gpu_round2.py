@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from tests.helpers import load_golden
+from tests.helpers import free_port, load_golden
 from tests.test_gpu_modules import assert_grad_norms, build, dev, dropout_eval, grad_norms, rel_err, run_seg
 
 pytestmark = pytest.mark.gpu
@@ -286,7 +286,7 @@ def test_syncbatchnorm_two_ranks_equal_one_rank_global_batch(tmp_path):
     out = tmp_path / "syncbn.txt"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29653", os.path.join(REPO, "tests", "_syncbn_worker.py"), str(out)]
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(REPO, "tests", "_syncbn_worker.py"), str(out)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = out.read_text().strip().splitlines()
@@ -314,7 +314,7 @@ def test_bench_two_ranks_strong_scaling_equal_the_one_rank_run(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(REPO, "bench.py"), "--gpus", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2",
                         "--scaling", "strong", "--sync-bn", "--dump", two] + common,
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

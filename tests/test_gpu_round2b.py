@@ -164,7 +164,8 @@ def test_bench_on_a_one_rank_rccl_group(tmp_path, mode):
     plain = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + common + extra(0), env=env,
                            capture_output=True, text=True, timeout=600)
     assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-4000:]
-    port = "29683" if mode == "eager" else "29684"
+    from tests.helpers import free_port
+    port = str(free_port())
     rccl = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                            "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(repo, "bench.py")] + common
                           + extra(1), env=dict(env, PCB_DIST_SINGLE="1"), capture_output=True, text=True, timeout=600)

@@ -105,6 +105,41 @@ def _worker(rank, world, port, tmp):
     one.reduce()
     torch.testing.assert_close(flat, one.flat, rtol=1e-6, atol=1e-7)
     assert float(flat[over.ranges[1][0]:over.ranges[1][1]].abs().max()) == 0.0   # the unused layer's slice
+    assert over.sent_order == [2, 1, 0]   # last bucket first, whatever order the buckets completed in
+
+    # a branch that receives a gradient on ONE rank only.  Its bucket completes during backward on that
+    # rank and only in finish() on the other; the collectives must still be issued in one order everywhere (the
+    # all-reduces have different sizes: a mismatch pairs slices of different buckets or hangs).
+    class Branchy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(6, 8)
+            self.side = nn.Linear(8, 8)
+            self.b = nn.Linear(8, 3)
+
+        def forward(self, x, use_side):
+            h = torch.relu(self.a(x))
+            if use_side:
+                h = h + self.side(h)
+            return self.b(h)
+
+    torch.manual_seed(4)
+    br = Branchy()
+    parallel.broadcast_parameters(br)
+    ob = parallel.OverlappedGradAllReduce.by_children(br)
+    ob.zero()
+    ((br(X[mine], rank == 0) - Y[mine]) ** 2).mean().backward()
+    got = ob.finish().clone()
+    assert ob.sent_order == [2, 1, 0]
+    ob.close()
+    # reference: both ranks' gradients computed here, missing ones as zeros, averaged
+    want = torch.zeros_like(got)
+    for r in range(world):
+        br.zero_grad(set_to_none=True)
+        rows = list(parallel.shard_scenes(8, r, world))
+        ((br(X[rows], r == 0) - Y[rows]) ** 2).mean().backward()
+        want += torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in br.parameters()]) / world
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-7)
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
