@@ -271,6 +271,10 @@ int pcb_edge_features_bwd(const float *grad_out, const int64_t *idx, int B, int 
 /* sums[0][c] += sum_r y[r][c]; sums[1][c] += sum_r y[r][c]^2.  sums [2,C] fp32, zeroed by the caller (any C that is a multiple of the chunk). */
 int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream);
 int pcb_colstats_f32(const void *y, long rows, int C, float *sums, void *stream);
+/* The same without atomics (reproducible mode): slabs [nparts][2][C], every one of the launch's nparts (1..2048)
+ * workgroups along the rows writes its own; pcb_bn_finalize / pcb_sum_slabs add them in slab order. */
+int pcb_colstats_slabs_bf16(const void *y, long rows, int C, float *slabs, int nparts, void *stream);
+int pcb_colstats_slabs_f32(const void *y, long rows, int C, float *slabs, int nparts, void *stream);
 
 /* out[i] = sum over k < nparts of slabs[k][i], i < n, in slab order (fp64 accumulation).  The local
  * totals of a [nparts][2][C] statistics buffer (n = 2C) -- what a SyncBatchNorm all-reduce carries. */
@@ -324,6 +328,15 @@ int pcb_bn_act_bwd_bf16(const void *dz, const void *y, const float *scale, const
 int pcb_bn_act_bwd_f32(const void *dz, const void *y, const float *scale, const float *shift,
                        const float *mean, const float *invstd, long rows, int C, int act,
                        int use_batch_stats, float *sums, void *dy, void *stream);
+
+/* The apply pass of pcb_bn_act_bwd_* alone, for totals sums [2,C] the caller formed itself (reproducible mode:
+ * pcb_bn_act_bwd_reduce_* in slab form + pcb_sum_slabs instead of the atomically accumulated single slab). */
+int pcb_bn_act_bwd_apply_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *mean,
+                              const float *invstd, const float *sums, long rows, int C, int act, int use_batch_stats,
+                              void *dy, void *stream);
+int pcb_bn_act_bwd_apply_f32(const void *dz, const void *y, const float *scale, const float *shift, const float *mean,
+                             const float *invstd, const float *sums, long rows, int C, int act, int use_batch_stats,
+                             void *dy, void *stream);
 
 /* Same for the pooled form: dout [groups,C] fp32 reaches only the arg-max rows; dy [groups*ns,C] bf16. */
 int pcb_bn_act_max_bwd_bf16(const float *dout, const unsigned char *argmax, const void *y,
@@ -749,11 +762,13 @@ int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, const void *
  *                         rows, with scale/shift/p/q as in pcb_gemm_nt_bf16 pro 2/3;
  *                         du[b*N + idx[r],:] += dy[r,:] (fp32 atomics, du zeroed by the caller),
  *                         dv[r/ns,:] = sum over the group (overwritten; may be NULL),
+ *                         det != 0: no atomics -- du is not touched (may be NULL: pcb_scatter_dy_csr_bf16 computes it)
+ *                         and dwx has pcb_scatter_dy_slabs(B,S,C,1) slabs;
  *                         dwx (may be NULL): fp32 [33][C][3], all zeroed by the caller; slab 0 receives
  *                         dWx[c,:] = sum_r dy[r,c] (x_j - c_s), slabs 1..32 are scratch (the atomic adds
  *                         are spread over them and summed at the end).
- * The stack calls take these through `gather` (NULL = ordinary stack): 12 int64 on the host,
- *   {u | du, v | dv, idx, B, N, S, ns, xyz, ctr, wx | dwx, ldw, 0}  (forward reads u, v, wx; backward
+ * The stack calls take these through `gather` (NULL = ordinary stack): 16 int64 on the host,
+ *   {u | du, v | dv, idx, B, N, S, ns, xyz, ctr, wx | dwx, ldw, flags (bit 0: det), order, offsets, 0, 0}  (forward reads u, v, wx; backward
  *   writes du, dv, dwx ([33][C][3], result in slab 0) and zeroes du, dwx first);
  * layer 0 of desc then carries no weight (slots [0],[7],[10] unused) and x, Kp, perm, dx are ignored.
  */
@@ -764,7 +779,32 @@ int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int 
 int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, const float *scale, const float *shift,
                         const float *p, const float *q, const float *dout, const unsigned char *argmax, int act,
                         const int64_t *idx, int B, int N, int S, int ns, int C, const float *xyz,
-                        const float *ctr, float *du, float *dv, float *dwx, void *stream);
+                        const float *ctr, float *du, float *dv, float *dwx, int det, void *stream);
+/* Slabs of the dwx buffer pcb_scatter_dy_bf16 needs ([slabs][C][3] floats, slab 0 = the result): 33, or -- det != 0 -- one
+ * per workgroup of the launch + 1. */
+long pcb_scatter_dy_slabs(int B, int S, int C, int det);
+
+/*
+ * Reproducible backward passes (no float atomics): the scatter-adds of the gathers' gradients -- the reference's
+ * index_put_(accumulate=True) behind index_points (models/pointnet2_utils.py:17-39), the grouping (:51-58, :342-349) and
+ * DGCNN.get_graph_feature (models/DGCNN.py:90-107) -- as segment sums over an inverted index in a FIXED order.
+ *   order [E] int32, offsets [T+1] int64: for target row t the source rows order[offsets[t] .. offsets[t+1]) that read
+ *   it, ascending (a stable sort of the targets; the Python side builds it with torch.sort, ops.det_index).
+ *   pcb_segment_sum_*       out[t, 0:C] (fp32, rows out_ld floats apart) = (accumulate ? out[t] : 0) + sum over the
+ *                           segment of rows[order[e]*ld + col0 + c], added in index order (rows fp32 or bf16)
+ *   pcb_scatter_dy_csr_bf16 du[t,:] = sum over the segment of dy[r,:], dy as pcb_scatter_dy_bf16 builds it; with
+ *                           pcb_scatter_dy_bf16(det = 1) (dv, dWx through per-workgroup slabs, du untouched / NULL) the
+ *                           backward of a gathered first layer without atomics.  The stack calls take det / order / offsets
+ *                           through slots [11] (bit 0), [12], [13] of `gather` (16 int64 then).
+ */
+int pcb_segment_sum_f32(const float *rows, long ld, int col0, int C, const int *order, const long long *offsets,
+                        long targets, float *out, long out_ld, int accumulate, void *stream);
+int pcb_segment_sum_bf16(const void *rows, long ld, int col0, int C, const int *order, const long long *offsets,
+                         long targets, float *out, long out_ld, int accumulate, void *stream);
+int pcb_scatter_dy_csr_bf16(int pooled, const void *dz, const void *y, const float *scale, const float *shift,
+                            const float *p, const float *q, const float *dout, const unsigned char *argmax, int act,
+                            int ns, int C, const int *order, const long long *offsets, long targets, float *du,
+                            void *stream);
 
 /* Raw fp32 input columns x [R, k] (rows `ld` floats apart: coordinates, colours) as a zero-padded operand
  * out [R, kp] of the row type (kp a multiple of 8 for bf16, 4 for fp32): cast + pad in one pass. */

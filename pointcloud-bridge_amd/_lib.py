@@ -42,6 +42,10 @@ SIGNATURES = {
     "pcb_edge_features_bwd": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_colstats_bf16": [_p, _l, _i, _p, _p],
     "pcb_colstats_f32": [_p, _l, _i, _p, _p],
+    "pcb_colstats_slabs_bf16": [_p, _l, _i, _p, _i, _p],
+    "pcb_colstats_slabs_f32": [_p, _l, _i, _p, _i, _p],
+    "pcb_bn_act_bwd_apply_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
+    "pcb_bn_act_bwd_apply_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
     "pcb_sum_slabs": [_p, _i, _i, _p, _p],
     "pcb_bn_finalize": [_p, _i, _l, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p],
     "pcb_set_concurrency_hint": [_i],
@@ -86,7 +90,11 @@ SIGNATURES = {
     "pcb_mlp_stack_backward": [_i, _i, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
     "pcb_gather_add_partials": [_l, _i],
     "pcb_gather_add_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p],
-    "pcb_scatter_dy_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "pcb_scatter_dy_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
+    "pcb_scatter_dy_slabs": [_i, _i, _i, _i],
+    "pcb_segment_sum_f32": [_p, _l, _i, _i, _p, _p, _l, _p, _l, _i, _p],
+    "pcb_segment_sum_bf16": [_p, _l, _i, _i, _p, _p, _l, _p, _l, _i, _p],
+    "pcb_scatter_dy_csr_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _l, _p, _p],
     "pcb_gate_bf16": [_p, _p, _p, _l, _p],
     "pcb_gate_f32": [_p, _p, _p, _l, _p],
     "pcb_gate_bwd_bf16": [_p, _p, _p, _p, _p, _l, _p],
@@ -154,7 +162,7 @@ def load():
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "pcb_status_string"
                           else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems", "pcb_mlp_stack_dzbuf_elems", "pcb_knn_xyz_workspace",
-                                                     "pcb_scene_max_workspace", "pcb_scene_colsum_workspace")
+                                                     "pcb_scene_max_workspace", "pcb_scene_colsum_workspace", "pcb_scatter_dy_slabs")
                           else ctypes.c_int)
         _lib = lib
     return _lib

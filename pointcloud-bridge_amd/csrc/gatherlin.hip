@@ -132,8 +132,11 @@ __global__ __launch_bounds__(kThreads) void scatter_dy_kernel(
     const float *__restrict__ dout, const unsigned char *__restrict__ arg, float slope,
     const int64_t *__restrict__ idx, int N, int S, int ns, int C, long G, float *__restrict__ du,
     float *__restrict__ dv, const float *__restrict__ xyz, const float *__restrict__ ctr,
-    float *__restrict__ dwx)
+    float *__restrict__ dwx, int det)
 {
+    // det != 0 (reproducible mode, see segsum.hip): no atomics at all -- du is left to pcb_scatter_dy_csr_bf16 (du may be
+    // NULL), and every workgroup adds its dWx partials into a slab of its OWN (dwx = [1 + gridDim.x][C][3], zeroed by the
+    // caller), summed in slab order afterwards.
     // the grid stride is a multiple of C (see the launcher): a lane keeps its column for good
     __shared__ float red[kThreads * 3];
     const long total = G * C;
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void scatter_dy_kernel(
             const float yv = bf2f(y[r * C + c]);
             const float f = POOLED ? (j == am ? d : 0.0f) : bf2f(dz[r * C + c]);
             if (src != run_src) {  // uniform over the lanes of a group
-                if (run_src >= 0) atomicAdd(&du[run_src * C + c], run);
+                if (run_src >= 0 && !det) atomicAdd(&du[run_src * C + c], run);
                 run = 0.0f;
                 run_src = src;
             }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void scatter_dy_kernel(
                 wacc2 = fmaf(dy, xyz[src * 3 + 2] - c2, wacc2);
             }
         }
-        if (run_src >= 0) atomicAdd(&du[run_src * C + c], run);
+        if (run_src >= 0 && !det) atomicAdd(&du[run_src * C + c], run);
         if (dv) dv[e] = acc;
     }
     if (dwx) {
@@ -200,21 +203,40 @@ __global__ __launch_bounds__(kThreads) void scatter_dy_kernel(
             }
             // thousands of workgroups adding into 3C addresses would queue up on them: the adds are
             // spread over kDwxSlabs copies (slabs 1..), summed into slab 0 by sum_slabs_kernel
-            float *slab = dwx + (long)(1 + blockIdx.x % kDwxSlabs) * C * 3;
-            atomicAdd(&slab[c * 3 + 0], a0);
-            atomicAdd(&slab[c * 3 + 1], a1);
-            atomicAdd(&slab[c * 3 + 2], a2);
+            if (det) {
+                // (one thread per column and workgroup reaches this point: plain stores into the workgroup's own slab)
+                float *own = dwx + (long)(1 + blockIdx.x) * C * 3;
+                own[c * 3 + 0] = a0;
+                own[c * 3 + 1] = a1;
+                own[c * 3 + 2] = a2;
+            } else {
+                float *slab = dwx + (long)(1 + blockIdx.x % kDwxSlabs) * C * 3;
+                atomicAdd(&slab[c * 3 + 0], a0);
+                atomicAdd(&slab[c * 3 + 1], a1);
+                atomicAdd(&slab[c * 3 + 2], a2);
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(kThreads) void sum_slabs_kernel(float *__restrict__ dwx, int elems)
+__global__ __launch_bounds__(kThreads) void sum_slabs_kernel(float *__restrict__ dwx, int elems, int nslabs)
 {
     const int e = blockIdx.x * kThreads + threadIdx.x;
     if (e >= elems) return;
     float a = 0.0f;
-    for (int k = 1; k <= kDwxSlabs; ++k) a += dwx[(long)k * elems + e];
+    for (int k = 1; k <= nslabs; ++k) a += dwx[(long)k * elems + e];
     dwx[e] = a;
+}
+
+// grid of scatter_dy_kernel: grid * 256 must be a multiple of C (a lane keeps its column): multiples of C / gcd(C, 256)
+inline long scatter_dy_grid(long G, int C)
+{
+    int gcd = C, t = kThreads;
+    while (t) { const int r = gcd % t; gcd = t; t = r; }
+    const long m = C / gcd;
+    long blocks = (G * C + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    return (blocks + m - 1) / m * m;
 }
 
 inline long gather_add_grid(long R, int C)
@@ -232,6 +254,12 @@ extern "C" int pcb_gather_add_partials(long R, int C)
 {
     if (R <= 0 || bad_c(C)) return 0;
     return (int)gather_add_grid(R, C);
+}
+
+extern "C" long pcb_scatter_dy_slabs(int B, int S, int C, int det)
+{
+    if (B <= 0 || S <= 0 || bad_c(C)) return 0;
+    return 1 + (det ? scatter_dy_grid((long)B * S, C) : kDwxSlabs);
 }
 
 extern "C" int pcb_gather_add_bf16(const float *u, const float *v, const int64_t *idx, int B, int N, int S,
@@ -253,30 +281,25 @@ extern "C" int pcb_scatter_dy_bf16(int pooled, const void *dz, const void *y, co
                                    const float *shift, const float *p, const float *q, const float *dout,
                                    const unsigned char *argmax, int act, const int64_t *idx, int B, int N,
                                    int S, int ns, int C, const float *xyz, const float *ctr, float *du, float *dv,
-                                   float *dwx, void *stream)
+                                   float *dwx, int det, void *stream)
 {
-    if (!y || !scale || !shift || !p || !q || !idx || !du || B <= 0 || N <= 0 || S <= 0 || ns <= 0)
+    if (!y || !scale || !shift || !p || !q || !idx || (!du && !det) || B <= 0 || N <= 0 || S <= 0 || ns <= 0)
         return PCB_ERR_INVALID_ARG;
     if (pooled ? (!dout || !argmax || ns > 255) : !dz) return PCB_ERR_INVALID_ARG;
     if (dwx && (!xyz || !ctr)) return PCB_ERR_INVALID_ARG;
     if (bad_c(C)) return PCB_ERR_UNSUPPORTED;
     const long G = (long)B * S;
-    // grid * 256 must be a multiple of C (a lane keeps its column): multiples of m = C / gcd(C, 256)
-    int gcd = C, t = kThreads;
-    while (t) { const int r = gcd % t; gcd = t; t = r; }
-    const long m = C / gcd;
-    long blocks = (G * C + kThreads - 1) / kThreads;
-    if (blocks > 4096) blocks = 4096;
-    blocks = (blocks + m - 1) / m * m;
+    const long blocks = scatter_dy_grid(G, C);
     hipStream_t st = (hipStream_t)stream;
     if (pooled)
         hipLaunchKernelGGL(scatter_dy_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), 0, st, (const u16 *)dz,
-                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv, xyz, ctr, dwx);
+                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv, xyz, ctr, dwx, det);
     else
         hipLaunchKernelGGL(scatter_dy_kernel<0>, dim3((unsigned)blocks), dim3(kThreads), 0, st, (const u16 *)dz,
-                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv, xyz, ctr, dwx);
+                           (const u16 *)y, scale, shift, p, q, dout, argmax, slope_of(act), idx, N, S, ns, C, G, du, dv, xyz, ctr, dwx, det);
     if (dwx)
-        hipLaunchKernelGGL(sum_slabs_kernel, dim3((3 * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, dwx, 3 * C);
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((3 * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, dwx, 3 * C,
+                           det ? (int)blocks : kDwxSlabs);
     pcb_account(6.0 * (double)G * ns * C + (pooled ? 5.0 * G * C : 2.0 * (double)G * ns * C) + 8.0 * G * ns);
     return pcb_check_launch();
 }

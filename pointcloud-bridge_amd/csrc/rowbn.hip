@@ -60,8 +60,10 @@ __device__ __forceinline__ void block_moments(const float *s, const float *q, in
 // of a wider matrix: blockIdx.y picks the block; the moments of column c go to sums[c], sums[Call + c]).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restrict__ y, long rows, int C, int Call,
-                                                             float *__restrict__ sums)
+                                                             float *__restrict__ sums, int slabs)
 {
+    // slabs != 0: sums is [gridDim.x][2][Call] and every workgroup along x writes its own slab (no atomics: the caller
+    // adds the slabs in order -- the reproducible mode); else one [2][Call] slab accumulated with atomics.
     constexpr int E = RowVec<T>::E;
     __shared__ float red[kThreads * 2 * E];
     const int c0 = blockIdx.y * C;             // first column of this block
@@ -95,7 +97,10 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const uint4 *__restr
         const int m = o / Cb, c = o % Cb;
         float a = 0.0f;
         for (int r = 0; r < RT; ++r) a += red[(r * CT + c / E) * 2 * E + m * E + (c % E)];
-        atomicAdd(&sums[(long)m * Call + c0 + c], a);
+        if (slabs)
+            sums[((long)blockIdx.x * 2 + m) * Call + c0 + c] = a;
+        else
+            atomicAdd(&sums[(long)m * Call + c0 + c], a);
     }
 }
 
@@ -588,17 +593,18 @@ inline bool bad_c(int C)
 
 // ---- typed launchers (the extern "C" entry points below are their two instantiations) -----------
 template <typename T>
-int colstats(const void *y, long rows, int C, float *sums, void *stream)
+int colstats(const void *y, long rows, int C, float *sums, int nparts, void *stream)
 {
     constexpr int E = RowVec<T>::E;
-    if (!y || !sums || rows <= 0) return PCB_ERR_INVALID_ARG;
+    if (!y || !sums || rows <= 0 || nparts < 0 || nparts > 2048) return PCB_ERR_INVALID_ARG;
     if (C <= 0 || (C % E) != 0) return PCB_ERR_UNSUPPORTED;
     // column blocks of at most 256 vectors (one lane per vector and row-lane)
     const int Cblk = C < 256 * E ? C : 256 * E;
     const int nblk = (C + Cblk - 1) / Cblk;
     const int RT = kThreads / (Cblk / E);
-    hipLaunchKernelGGL(colstats_kernel<T>, dim3(grid_for(rows, RT * 8, 2048), nblk), dim3(kThreads), 0,
-                       (hipStream_t)stream, (const uint4 *)y, rows, Cblk, C, sums);
+    // nparts > 0: the caller's slab count IS the grid along the rows (slab mode: [nparts][2][C], no atomics)
+    hipLaunchKernelGGL(colstats_kernel<T>, dim3(nparts > 0 ? nparts : grid_for(rows, RT * 8, 2048), nblk), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const uint4 *)y, rows, Cblk, C, sums, nparts > 0 ? 1 : 0);
     pcb_account((double)sizeof(T) * rows * C);
     return pcb_check_launch();
 }
@@ -675,6 +681,23 @@ int bn_act_bwd(const void *dz, const void *y, const float *scale, const float *s
     // sums [2,C] must be zero on entry; it returns (dbeta, dgamma) = (s1, s2)
     const int st = bn_act_bwd_reduce<T>(dz, y, scale, shift, mean, invstd, rows, C, act, sums, 1, stream);
     if (st != PCB_OK) return st;
+    const int RT = kThreads / (C / RowVec<T>::E);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(rows, RT * 4, 2048)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd, sums, rows, C, slope_of(act),
+                       use_batch_stats, (uint4 *)dy);
+    pcb_account(3.0 * sizeof(T) * rows * C);
+    return pcb_check_launch();
+}
+
+// the apply pass alone: sums [2,C] = (s1, s2) of bn_act_bwd_reduce, totals given by the caller (reproducible mode: the
+// slab form of the reduction + pcb_sum_slabs)
+template <typename T>
+int bn_act_bwd_apply(const void *dz, const void *y, const float *scale, const float *shift, const float *mean,
+                     const float *invstd, const float *sums, long rows, int C, int act, int use_batch_stats, void *dy,
+                     void *stream)
+{
+    if (!dz || !y || !scale || !shift || !mean || !invstd || !sums || !dy || rows <= 0) return PCB_ERR_INVALID_ARG;
+    if (bad_c<T>(C)) return PCB_ERR_UNSUPPORTED;
     const int RT = kThreads / (C / RowVec<T>::E);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(rows, RT * 4, 2048)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4 *)dz, (const uint4 *)y, scale, shift, mean, invstd, sums, rows, C, slope_of(act),
@@ -766,8 +789,29 @@ int gate_bwd(const void *g, const void *x, const void *a, void *dx, void *da, lo
 
 extern "C" {
 
-int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream) { return colstats<pcb_bf16>(y, rows, C, sums, stream); }
-int pcb_colstats_f32(const void *y, long rows, int C, float *sums, void *stream) { return colstats<float>(y, rows, C, sums, stream); }
+int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream) { return colstats<pcb_bf16>(y, rows, C, sums, 0, stream); }
+int pcb_colstats_f32(const void *y, long rows, int C, float *sums, void *stream) { return colstats<float>(y, rows, C, sums, 0, stream); }
+int pcb_colstats_slabs_bf16(const void *y, long rows, int C, float *slabs, int nparts, void *stream)
+{
+    return nparts < 1 ? PCB_ERR_INVALID_ARG : colstats<pcb_bf16>(y, rows, C, slabs, nparts, stream);
+}
+int pcb_colstats_slabs_f32(const void *y, long rows, int C, float *slabs, int nparts, void *stream)
+{
+    return nparts < 1 ? PCB_ERR_INVALID_ARG : colstats<float>(y, rows, C, slabs, nparts, stream);
+}
+
+int pcb_bn_act_bwd_apply_bf16(const void *dz, const void *y, const float *scale, const float *shift, const float *mean,
+                              const float *invstd, const float *sums, long rows, int C, int act, int use_batch_stats,
+                              void *dy, void *stream)
+{
+    return bn_act_bwd_apply<pcb_bf16>(dz, y, scale, shift, mean, invstd, sums, rows, C, act, use_batch_stats, dy, stream);
+}
+int pcb_bn_act_bwd_apply_f32(const void *dz, const void *y, const float *scale, const float *shift, const float *mean,
+                             const float *invstd, const float *sums, long rows, int C, int act, int use_batch_stats,
+                             void *dy, void *stream)
+{
+    return bn_act_bwd_apply<float>(dz, y, scale, shift, mean, invstd, sums, rows, C, act, use_batch_stats, dy, stream);
+}
 
 int pcb_sum_slabs(const float *slabs, int nparts, int n, float *out, void *stream)
 {

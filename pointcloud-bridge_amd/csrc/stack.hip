@@ -393,6 +393,9 @@ struct Gather {
     const float *xyz, *ctr;  // optional coordinate term Wx (x_j - c_s)
     float *wx;               // forward: Wx [C,3] with row stride ldw;  backward: dWx [C,3]
     int ldw;
+    int det;                        // backward: reproducible mode (no atomics; segsum.hip)
+    const int *order;               // det: inverted index of idx (ops.det_index): grouped rows by source point
+    const long long *offsets;       //      [B*N + 1]
 };
 bool parse_gather(const long long *g, Gather *out)
 {
@@ -408,6 +411,9 @@ bool parse_gather(const long long *g, Gather *out)
     out->ctr = ptr<const float>(g[8]);
     out->wx = ptr<float>(g[9]);
     out->ldw = (int)g[10];
+    out->det = (int)(g[11] & 1);
+    out->order = ptr<const int>(g[12]);
+    out->offsets = ptr<const long long>(g[13]);
     return true;
 }
 }  // namespace
@@ -670,11 +676,23 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
             if (gathered && l == 0) {
                 // gathered layer: its input gradients are du (per source point) and dv (per centroid)
                 if (pooled && pool != ga.ns) return PCB_ERR_INVALID_ARG;
-                if (pcb_zero2_async(ga.u, sizeof(float) * (size_t)ga.B * ga.N * a.C, ga.wx, sizeof(float) * 3 * a.C * 33,
+                if (ga.det && (!ga.order || !ga.offsets)) return PCB_ERR_INVALID_ARG;
+                const size_t wx_floats = (size_t)3 * a.C * pcb_scatter_dy_slabs(ga.B, ga.S, a.C, ga.det);
+                if (ga.det) {
+                    // reproducible mode: du by a segment sum over the inverted index (every row of du is written: no
+                    // clearing), dv / dWx by the row-order pass without atomics
+                    if (ga.wx && pcb_zero_async(ga.wx, sizeof(float) * wx_floats, main_st) != PCB_OK) return PCB_ERR_LAUNCH;
+                    PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx, ga.B,
+                                                ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, nullptr, ga.v, ga.wx, 1, stream));
+                    PCB_TRY(pcb_scatter_dy_csr_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.ns, a.C,
+                                                    ga.order, ga.offsets, (long)ga.B * ga.N, ga.u, stream));
+                    return PCB_OK;
+                }
+                if (pcb_zero2_async(ga.u, sizeof(float) * (size_t)ga.B * ga.N * a.C, ga.wx, sizeof(float) * wx_floats,
                                     main_st) != PCB_OK)
                     return PCB_ERR_LAUNCH;
                 PCB_TRY(pcb_scatter_dy_bf16(pooled ? 1 : 0, dz, a.y, scale, shift, p, q, dout, argmax, act, ga.idx,
-                                            ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.u, ga.v, ga.wx, stream));
+                                            ga.B, ga.N, ga.S, ga.ns, a.C, ga.xyz, ga.ctr, ga.u, ga.v, ga.wx, 0, stream));
                 return PCB_OK;
             }
             if (a.ext && a.ext[X_DADD1]) {

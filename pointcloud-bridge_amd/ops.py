@@ -346,6 +346,53 @@ def structure_features(xyz, idx, with_offsets=True):
 
 
 # --------------------------------------------------------------------------------------------
+# reproducible mode
+# --------------------------------------------------------------------------------------------
+# The gradients of the gathers are scatter-adds (the reference's index_put_(accumulate=True) behind index_points,
+# the grouping and get_graph_feature).  By default they run as fp32 atomics at memory: the fastest form on this chip,
+# but the order of the additions varies from run to run.  In the reproducible mode every backward pass of this package
+# sums in a fixed order instead (csrc/segsum.hip over an inverted index, slab sums in the BatchNorm kernels) and two
+# runs of one training command give bit-identical gradients.  It is on when set_deterministic(True) was called, when
+# the environment says PCB_DETERMINISTIC=1, or when torch.use_deterministic_algorithms(True) is in force.
+_deterministic = os.environ.get("PCB_DETERMINISTIC", "0") != "0"
+
+
+def set_deterministic(flag):
+    """Reproducible backward passes on / off for this process; returns the previous setting."""
+    global _deterministic
+    old, _deterministic = _deterministic, bool(flag)
+    return old
+
+
+def deterministic():
+    return _deterministic or torch.are_deterministic_algorithms_enabled()
+
+
+def det_index(idx, n_targets):
+    """Inverted index of a gather whose source rows read target rows idx [B, ...] (values clamped to [0, n_targets),
+    per scene): (order int32 [E], offsets int64 [B * n_targets + 1]) -- for global target row t the global source rows
+    order[offsets[t] : offsets[t + 1]], ascending (torch.sort with stable=True: rocPRIM's radix sort, deterministic)."""
+    B = idx.shape[0]
+    flat = idx.reshape(B, -1).clamp(0, n_targets - 1)
+    tgt = (flat + torch.arange(B, device=idx.device).view(B, 1) * n_targets).reshape(-1)
+    key, order = torch.sort(tgt, stable=True)
+    offsets = torch.searchsorted(key, torch.arange(B * n_targets + 1, device=idx.device))
+    return order.to(torch.int32), offsets.contiguous()
+
+
+def segment_sum(rows, col0, C, order, offsets, out, accumulate=False):
+    """out[t, :C] (fp32 rows) = (out[t] if accumulate else 0) + sum over the segment of rows[order[e], col0 : col0 + C]
+    in index order; rows: 2-D fp32 or bf16 with contiguous rows."""
+    sfx = {torch.float32: "f32", torch.bfloat16: "bf16"}[rows.dtype]
+    if rows.dim() != 2 or rows.stride(1) != 1 or out.dim() != 2 or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError("segment_sum: 2-D rows and fp32 2-D out with contiguous rows")
+    with on_device(rows.device):
+        _launch("pcb_segment_sum_" + sfx, order.numel() * C, rows.data_ptr(), rows.stride(0), int(col0), int(C), order.data_ptr(),
+                offsets.data_ptr(), out.shape[0], out.data_ptr(), out.stride(0), int(bool(accumulate)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # differentiable ops
 # --------------------------------------------------------------------------------------------
 class _GatherRows(torch.autograd.Function):
@@ -365,6 +412,10 @@ class _GatherRows(torch.autograd.Function):
         (idx_flat,) = ctx.saved_tensors
         B, N, C, M = ctx.shape
         g = g.contiguous()
+        if deterministic():
+            gp = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+            segment_sum(g.view(B * M, C), 0, C, *det_index(idx_flat, N), gp.view(B * N, C))
+            return gp, None
         gp = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
         with on_device(g.device):
             _launch("pcb_gather_rows_bwd", B * M * C, g.data_ptr(), idx_flat.data_ptr(), B, N, C, M, gp.data_ptr())
@@ -405,6 +456,10 @@ class _GroupPoints(torch.autograd.Function):
         if C == 0 or not ctx.needs_input_grad[2]:
             return None, None, None, None
         g = g.contiguous()
+        if deterministic():
+            gf = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+            segment_sum(g.view(B * S * ns, 3 + C), 3, C, *det_index(idx, N), gf.view(B * N, C))
+            return None, None, gf, None
         gf = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
         with on_device(g.device):
             _launch("pcb_group_points_bwd", B * S * ns * C, g.data_ptr(), idx.data_ptr(), B, N, S, ns, C, gf.data_ptr())
@@ -445,6 +500,15 @@ class _ThreeInterpolate(torch.autograd.Function):
         w, idx = ctx.saved_tensors
         B, N, S, C, k = ctx.shape
         g = g.contiguous()
+        if deterministic() and C % 4 == 0:
+            # weighted segment sum over the inverted index, entries ascending (the CSR kernel of the row engine)
+            order, offsets = det_index(idx, S)
+            entries = (order % (N * k)).to(torch.int32)
+            gf = torch.empty(B, S, C, dtype=torch.float32, device=g.device)
+            with on_device(g.device):
+                _launch("pcb_interpolate_bwd_csr_f32", B * N * C * k, g.data_ptr(), C, 0, w.data_ptr(), offsets.data_ptr(),
+                        entries.data_ptr(), B, N, S, C, k, gf.data_ptr())
+            return gf, None, None
         gf = torch.zeros(B, S, C, dtype=torch.float32, device=g.device)
         with on_device(g.device):
             _launch("pcb_interpolate_bwd", B * N * C, g.data_ptr(), w.data_ptr(), idx.data_ptr(), B, N, S, C, k, gf.data_ptr())
@@ -481,6 +545,12 @@ class _EdgeFeatures(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, D, k = ctx.shape
         g = g.contiguous()
+        if deterministic():
+            # centre term: sum over the point's own k rows (a dense reduction); neighbour terms: segment sum
+            g4 = g.view(B, N, k, 2 * D)
+            gx = (g4[..., D:] - g4[..., :D]).sum(dim=2).contiguous()
+            segment_sum(g.view(B * N * k, 2 * D), 0, D, *det_index(idx, N), gx.view(B * N, D), accumulate=True)
+            return gx, None
         gx = torch.zeros(B, N, D, dtype=torch.float32, device=g.device)
         with on_device(g.device):
             _launch("pcb_edge_features_bwd", B * N * k * 2 * D, g.data_ptr(), idx.data_ptr(), B, N, D, k, gx.data_ptr())

@@ -31,6 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from . import ops as _ops
 from .ops import _launch, apply_concurrency_hint, on_device
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
@@ -901,10 +902,10 @@ class _GatheredStack(torch.autograd.Function):
             else:
                 wbuf = torch.empty(max(nw, 1), dtype=torch.bfloat16, device=dev)
         fdesc = (ctypes.c_double * (2 * L))(*[float(x) for t in layers for x in (t[7], t[8])])
-        gather = (ctypes.c_longlong * 12)(
+        gather = (ctypes.c_longlong * 16)(
             u.data_ptr(), 0 if v is None else v.data_ptr(), idx.data_ptr(), B, N, S, ns,
             0 if wx is None else xyz.data_ptr(), 0 if wx is None else ctr.data_ptr(),
-            0 if wx is None else wx.data_ptr(), 3 if wx is None else wx.stride(0), 0)
+            0 if wx is None else wx.data_ptr(), 3 if wx is None else wx.stride(0), 0, 0, 0, 0, 0)
         C = widths[-1]
         if pool:
             out = torch.empty(R // pool, C, dtype=torch.bfloat16, device=dev)
@@ -918,8 +919,11 @@ class _GatheredStack(torch.autograd.Function):
                     0 if arg is None else arg.data_ptr())
         if cache_key is not None and not ready:
             _eval_store(cache_key, first, versions, (wbuf, stz))
+        # reproducible mode: the inverted index of the gather (source point -> grouped rows) for the backward pass
+        # (grad mode is off inside a Function's forward: needs_input_grad says whether a backward pass can follow)
+        det = _ops.det_index(idx, N) if (_ops.deterministic() and any(ctx.needs_input_grad)) else (None, None)
         ctx.save_for_backward(idx, arg, ybuf, stz, wbuf, xyz if wx is not None else None,
-                              ctr if wx is not None else None, *[t[0] for t in layers[1:]])
+                              ctr if wx is not None else None, det[0], det[1], *[t[0] for t in layers[1:]])
         ctx.cfg = (act, pool, L, ns, B, N, S, widths, v is not None, wx is not None,
                    [(t[1] is not None, t[2] is not None, bool(t[6])) for t in layers])
         return out
@@ -929,8 +933,9 @@ class _GatheredStack(torch.autograd.Function):
         act, pool, L, ns, B, N, S, widths, has_v, has_wx, flags = ctx.cfg
         m = _MODES["bf16"]
         saved = ctx.saved_tensors
-        idx, arg, ybuf, stz, wbuf, xyz, ctr = saved[:7]
-        weights = [None] + list(saved[7:7 + L - 1])
+        idx, arg, ybuf, stz, wbuf, xyz, ctr, order, offsets = saved[:9]
+        weights = [None] + list(saved[9:9 + L - 1])
+        det = order is not None
         dev = idx.device
         R = B * S * ns
         lib = _lib.load()
@@ -952,13 +957,15 @@ class _GatheredStack(torch.autograd.Function):
             outs.append((dw, dgamma, dbeta, dbias))
         layers = [(weights[l], None, None, None, None, None, flags[l][2]) for l in range(L)]
         desc = _stack_desc(layers, widths, ybuf, R, m, outs)
-        du = torch.empty(B * N, widths[0], dtype=torch.float32, device=dev)   # zeroed by the library
+        du = torch.empty(B * N, widths[0], dtype=torch.float32, device=dev)   # zeroed / fully written by the library
         dv = torch.empty(B * S, widths[0], dtype=torch.float32, device=dev) if has_v else None
-        dwx = torch.empty(33, widths[0], 3, dtype=torch.float32, device=dev) if has_wx else None  # [0] = result
-        gather = (ctypes.c_longlong * 12)(
+        slabs = lib.pcb_scatter_dy_slabs(B, S, widths[0], int(det))
+        dwx = torch.empty(slabs, widths[0], 3, dtype=torch.float32, device=dev) if has_wx else None  # [0] = result
+        gather = (ctypes.c_longlong * 16)(
             du.data_ptr(), 0 if dv is None else dv.data_ptr(), idx.data_ptr(), B, N, S, ns,
             0 if dwx is None else xyz.data_ptr(), 0 if dwx is None else ctr.data_ptr(),
-            0 if dwx is None else dwx.data_ptr(), 3, 0)
+            0 if dwx is None else dwx.data_ptr(), 3, int(det), order.data_ptr() if det else 0,
+            offsets.data_ptr() if det else 0, 0, 0)
         nz = lib.pcb_mlp_stack_dzbuf_elems(_MODES["bf16"].code, L, desc, R, 0, pool, 1)
         dzbuf = torch.empty(nz, dtype=torch.bfloat16, device=dev) if nz else None
         parts = torch.empty(_MAX_PARTS * 2 * max(widths), dtype=torch.float32, device=dev)
@@ -1186,7 +1193,13 @@ class _LinearBias(torch.autograd.Function):
             else:
                 _launch("pcb_gemm_tn_" + m.sfx, 2 * R * (npad + kp), 0, gy.data_ptr(), 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, x.data_ptr(),
                         0, 0, 0, R, npad, kp, ws.data_ptr(), dw.data_ptr(), k, 0)
-                if has_bias:
+                if has_bias and _ops.deterministic():
+                    nparts = max(1, min(256, R // 64))
+                    slabs = torch.empty(nparts, 2, npad, dtype=torch.float32, device=dev)
+                    _launch("pcb_colstats_slabs_" + m.sfx, R * npad, gy.data_ptr(), R, npad, slabs.data_ptr(), nparts)
+                    _launch("pcb_sum_slabs", 2 * npad, slabs.data_ptr(), nparts, 2 * npad, sums.data_ptr())
+                    db = sums[0]
+                elif has_bias:
                     _launch("pcb_colstats_" + m.sfx, R * npad, gy.data_ptr(), R, npad, sums.data_ptr())
                     db = sums[0]
         gres = g if ctx.has_res else None   # d(out)/d(res) = identity
@@ -1218,6 +1231,11 @@ def build_interp_csr(idx, S):
     [B*N*k] int32).  Depends on the coordinates only, so a prefetch can build it ahead."""
     B, N, k = idx.shape
     dev = idx.device
+    if _ops.deterministic():
+        # reproducible mode: entries of a segment in ascending order (the counting sort below places them in the order
+        # its atomic cursors are served, and the consumer adds in entry order)
+        order, offsets = _ops.det_index(idx, S)
+        return offsets, (order % (N * k)).to(torch.int32)
     count = torch.zeros(2, B * S, dtype=torch.int32, device=dev)  # counts | placement cursors
     entries = torch.empty(B * N * k, dtype=torch.int32, device=dev)
     with on_device(dev):
@@ -1296,11 +1314,17 @@ class _BNActRows(torch.autograd.Function):
         stats = torch.zeros(6, C, dtype=torch.float32, device=dev)  # sums(2) | scale | shift | mean | invstd
         out = torch.empty(R, C, dtype=m.dtype, device=dev)
         if training:
-            note_parameter_update()
+            note_parameter_update(weights=False)   # running statistics only: prepared operands of other stacks stay valid
+        sums, nparts = stats[0:2], 1
         with on_device(dev):
-            if training:
+            if training and _ops.deterministic():
+                # reproducible mode: one slab per workgroup, added in slab order by the finalize kernel (no atomics)
+                nparts = max(1, min(256, R // 64))
+                sums = torch.empty(nparts, 2, C, dtype=torch.float32, device=dev)
+                _launch("pcb_colstats_slabs_" + m.sfx, R * C, y.data_ptr(), R, C, sums.data_ptr(), nparts)
+            elif training:
                 _launch("pcb_colstats_" + m.sfx, R * C, y.data_ptr(), R, C, stats[0:2].data_ptr())
-            _launch("pcb_bn_finalize", C, stats[0:2].data_ptr(), 1, R, 0, C,
+            _launch("pcb_bn_finalize", C, sums.data_ptr(), nparts, R, 0, C,
                     0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(), 0,
                     0 if running_mean is None else running_mean.data_ptr(),
                     0 if running_var is None else running_var.data_ptr(),
@@ -1322,8 +1346,19 @@ class _BNActRows(torch.autograd.Function):
         dy = torch.empty(R, C, dtype=m.dtype, device=dev)
         gb = g.to(m.dtype).contiguous()
         with on_device(dev):
-            _launch("pcb_bn_act_bwd_" + m.sfx, R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-                    stats[4].data_ptr(), stats[5].data_ptr(), R, C, act, training, bsums.data_ptr(), dy.data_ptr())
+            if _ops.deterministic():
+                # the reduction in slab form, its totals in slab order, then the apply pass (no atomics)
+                nparts = max(2, min(256, R // 64))
+                slabs = torch.empty(nparts, 2, C, dtype=torch.float32, device=dev)
+                _launch("pcb_bn_act_bwd_reduce_" + m.sfx, R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(),
+                        stats[3].data_ptr(), stats[4].data_ptr(), stats[5].data_ptr(), R, C, act, slabs.data_ptr(), nparts)
+                _launch("pcb_sum_slabs", 2 * C, slabs.data_ptr(), nparts, 2 * C, bsums.data_ptr())
+                _launch("pcb_bn_act_bwd_apply_" + m.sfx, R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(),
+                        stats[3].data_ptr(), stats[4].data_ptr(), stats[5].data_ptr(), bsums.data_ptr(), R, C, act, training,
+                        dy.data_ptr())
+            else:
+                _launch("pcb_bn_act_bwd_" + m.sfx, R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                        stats[4].data_ptr(), stats[5].data_ptr(), R, C, act, training, bsums.data_ptr(), dy.data_ptr())
         return (dy, bsums[1].clone() if has_affine else None, bsums[0].clone() if has_affine else None,
                 None, None, None, None, None, None, None, None)
 
@@ -1569,6 +1604,10 @@ class _GroupRows(torch.autograd.Function):
         if C == 0 or not ctx.needs_input_grad[2]:
             return None, None, None, None, None
         g = g.to(m.dtype).contiguous()
+        if _ops.deterministic():
+            gf = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+            _ops.segment_sum(g.view(B * S * ns, kp), 0, C, *_ops.det_index(idx, N), gf.view(B * N, C))
+            return None, None, gf, None, None
         gf = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
         with on_device(g.device):
             _launch("pcb_group_rows_%s_bwd" % m.sfx, B * S * ns * C, g.data_ptr(), idx.data_ptr(), B, N, S, ns, C, kp,

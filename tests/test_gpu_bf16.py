@@ -80,9 +80,8 @@ def test_linear_bn_act_forward_backward_vs_torch_fp32(rm, R, K, C, act, pool):
     bn_ref = nn.BatchNorm1d(C).to(dev).train()
     bn_ref.load_state_dict(bn.state_dict())
 
-    rm.set_precision("bf16")
-    out = rm.conv_bn_act(conv, bn, x, act, pool)
-    rm.set_precision("fp32")
+    with rm.precision("bf16"):
+        out = rm.conv_bn_act(conv, bn, x, act, pool)
     assert out.dtype == torch.bfloat16 and out.shape == (R // pool if pool else R, C)
 
     # reference: fp32 math on the same bf16-rounded operands; y rounded to bf16 as the kernels store it
@@ -132,9 +131,8 @@ def test_fused_stack_forward_backward_vs_torch_fp32(rm, R, K, widths, act, pool,
             rf.load_state_dict(bn.state_dict())
         if perm:
             x.data[:, kin:] = 0          # padding columns as pcb_group_rows_bf16 writes them
-    rm.set_precision("bf16")
-    out = rm.mlp_rows(convs, bns, x, act, pool, perm)
-    rm.set_precision("fp32")
+    with rm.precision("bf16"):
+        out = rm.mlp_rows(convs, bns, x, act, pool, perm)
 
     xr = x.detach().float().requires_grad_(True)
     h = xr[:, :kin]
@@ -172,9 +170,8 @@ def test_eval_mode_uses_running_stats_and_bias(rm):
         bn.running_mean.uniform_(-1, 1)
         bn.running_var.uniform_(0.5, 2)
     bn.eval()
-    rm.set_precision("bf16")
-    out = rm.conv_bn_act(conv, bn, x, 1)
-    rm.set_precision("fp32")
+    with rm.precision("bf16"):
+        out = rm.conv_bn_act(conv, bn, x, 1)
     ref = F.relu(bn(F.linear(x.to(torch.bfloat16).float(), conv.weight.view(C, K).to(torch.bfloat16).float(), conv.bias)))
     assert float((out.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
 
@@ -187,9 +184,8 @@ def test_group_rows_bf16_layout_and_backward(rm):
     new_xyz = xyz[:, :S].contiguous()
     feat = torch.randn(B, N, C, device="cuda").to(torch.bfloat16).requires_grad_(True)
     idx = torch.randint(0, N, (B, S, ns), device="cuda")
-    rm.set_precision("bf16")
-    rows, perm = rm.group_rows(xyz, new_xyz, feat, idx)
-    rm.set_precision("fp32")
+    with rm.precision("bf16"):
+        rows, perm = rm.group_rows(xyz, new_xyz, feat, idx)
     assert perm == C and rows.shape == (B * S * ns, 24) and rows.dtype == torch.bfloat16
     ref = ops.group_points(xyz, new_xyz, feat.detach().float(), idx).view(-1, 3 + C)
     assert torch.equal(rows[:, :C].float(), ref[:, 3:])                       # features first, exact copy
@@ -221,12 +217,11 @@ def test_bf16_networks_track_fp32_networks(rm, name):
         for m in model.modules():
             if isinstance(m, nn.Dropout):
                 m.eval()
-        rm.set_precision(mode)
-        torch.manual_seed(9)
-        logits = model(xyz, colors)
-        loss = bench.loss_fn(logits, labels, cdim)
-        loss.backward()
-        rm.set_precision("fp32")
+        with rm.precision(mode):
+            torch.manual_seed(9)
+            logits = model(xyz, colors)
+            loss = bench.loss_fn(logits, labels, cdim)
+            loss.backward()
         gn = torch.stack([p.grad.norm() for p in model.parameters() if p.grad is not None])
         res[mode] = (logits.detach().float(), float(loss), gn)
     l32, l16 = res["fp32"][0], res["bf16"][0]
@@ -248,34 +243,58 @@ def test_bf16_networks_track_fp32_networks(rm, name):
 
 
 def test_bf16_training_reaches_fp32_miou(rm):
-    """Short training on a learnable synthetic task: mIoU (inference.py:814-855 definition) of the
-    bf16 mode within 7 points of the fp32 mode.  (Each mode alone varies by +-2.5 points from run to
-    run at this length -- fp32 atomics in the gather backward passes make training chaotic -- so the
-    bar is the spread of two such runs plus a margin, tools/miou_flake.py.)"""
-    from pointcloud_bridge_amd import train
+    """Short trainings on a learnable synthetic task: mIoU (inference.py:814-855 definition) of the bf16 engine against
+    the fp32 engine, in the REPRODUCIBLE mode (ops.set_deterministic: no float atomics anywhere in the step).
+
+    Round 2 ran this once per mode with atomics and needed a 7-point bar, blaming the atomics' run-to-run drift (+-2.5
+    points).  With the drift gone (a run repeated here gives the same mIoU to the last bit) the picture is: the
+    DIFFERENCE between the two engines at a given seed and step is itself a chaotic quantity -- SGD on 8 scenes
+    amplifies any rounding difference, and the validation mIoU of either engine moves by +-3 points from one
+    checkpoint to the next (tools/miou_det.py: -4.3 ... +5.4 points over 4 model seeds x 3 checkpoints) -- while its
+    MEAN over those 12 samples is 0.06 points: the bf16 engine carries no systematic mIoU offset.  Asserted: the mean
+    within 1 point (measured 0.06), every sample within 7."""
+    from pointcloud_bridge_amd import ops, train
     from pointcloud_bridge_amd.models.containers import PointNet2
+    from pointcloud_bridge_amd.models.pointnet2_utils import FeaturePropagation
     enc = [(256, 0.2, 16, 6, [32, 32, 64]), (64, 0.4, 16, 67, [64, 64, 128]), (16, 0.8, 16, 131, [128, 128, 256])]
     data = train.synthetic_scenes(8, 1024, seed=0, device="cuda")
     val = train.synthetic_scenes(4, 1024, seed=1, device="cuda")
-    miou = {}
-    for mode in ("fp32", "bf16"):
-        torch.manual_seed(42)
+    checkpoints = (60, 120, 240)
+
+    def run(mode, seed):
+        torch.manual_seed(seed)
         model = PointNet2(5, encoder=enc)
         # decoder widths follow the encoder of this small variant
-        from pointcloud_bridge_amd.models.pointnet2_utils import FeaturePropagation
         model.fp3 = FeaturePropagation(256 + 128, [128, 128])
         model.fp2 = FeaturePropagation(128 + 64, [128, 64])
         model.fp1 = FeaturePropagation(64, [128, 128, 128])
         model = model.cuda()
-        rm.set_precision(mode)
-        tr = train.Trainer(model, 5, lr=2e-3)
-        torch.manual_seed(0)
-        for _ in range(120):
-            tr.train_step(data)
-        miou[mode] = tr.evaluate([val])["miou"]
-        rm.set_precision("fp32")
-    assert miou["fp32"] > 0.6 and miou["bf16"] > 0.6, miou
-    assert abs(miou["bf16"] - miou["fp32"]) < 0.07, miou
+        with rm.precision(mode):
+            tr = train.Trainer(model, 5, lr=2e-3)
+            torch.manual_seed(0)
+            torch.cuda.manual_seed(0)
+            hist = []
+            for i in range(max(checkpoints)):
+                tr.train_step(data)
+                if i + 1 in checkpoints:
+                    hist.append(tr.evaluate([val])["miou"])
+        return hist
+
+    old = ops.set_deterministic(True)
+    try:
+        diffs = []
+        for seed in (42, 43, 44, 45):
+            f32, b16 = run("fp32", seed), run("bf16", seed)
+            print("seed", seed, "fp32", [round(v, 4) for v in f32], "bf16", [round(v, 4) for v in b16])
+            assert min(f32 + b16) > 0.6           # both engines learn the task (chance: 0.2)
+            diffs += [b - f for f, b in zip(f32, b16)]
+        assert run("bf16", 45) == b16             # reproducible: the same trajectory, bit for bit
+    finally:
+        ops.set_deterministic(old)
+    mean = sum(diffs) / len(diffs)
+    print("bf16 - fp32 mIoU over", len(diffs), "samples: mean", round(mean, 4), "min", round(min(diffs), 4), "max", round(max(diffs), 4))
+    assert abs(mean) < 0.01
+    assert max(abs(d) for d in diffs) < 0.07
 
 
 @pytest.mark.parametrize("D1,C,k", [(3, 64, 4), (0, 32, 3), (16, 256, 4), (5, 8, 3)])
@@ -290,11 +309,8 @@ def test_interpolate_concat_bf16_forward_backward(rm, D1, C, k):
     feat = torch.randn(B, S, C, generator=g).cuda().to(torch.bfloat16).requires_grad_(True)
     skip = torch.randn(B * N, D1, generator=g).cuda().to(torch.bfloat16).requires_grad_(True) if D1 else None
     d2, idx = ops.three_nn(xyz1, xyz2, k)
-    rm.set_precision("bf16")
-    try:
+    with rm.precision("bf16"):
         rows, perm = rm.interpolate_concat(skip, feat, d2, idx)
-    finally:
-        rm.set_precision("fp32")
     dp = (D1 + 7) // 8 * 8
     assert rows.shape == (B * N, dp + C) and perm == (-D1 if D1 % 8 else 0)
     ref_feat = feat.detach().float().requires_grad_(True)
@@ -560,7 +576,7 @@ def test_gather_add_and_scatter_dy_entry_points(rm, pooled, with_v, with_wx, C):
     _launch("pcb_scatter_dy_bf16", 0, pooled, 0 if dz is None else dz.data_ptr(), y.data_ptr(), scale.data_ptr(),
             shift.data_ptr(), p.data_ptr(), q.data_ptr(), 0 if dout is None else dout.data_ptr(),
             0 if arg is None else arg.data_ptr(), 1, idx.data_ptr(), B, N, S, ns, C, xyz.data_ptr(), ctr.data_ptr(),
-            du.data_ptr(), dv.data_ptr(), 0 if dwx is None else dwx.data_ptr())
+            du.data_ptr(), dv.data_ptr(), 0 if dwx is None else dwx.data_ptr(), 0)
     du_ref = torch.zeros(B * N, C, device=dev).index_add_(0, src, dy)
     dv_ref = dy.view(B * S, ns, C).sum(1)
     assert torch.allclose(du, du_ref, rtol=1e-4, atol=1e-4)
@@ -576,13 +592,10 @@ def test_gate_rows_matches_torch(rm):
     x = torch.randn(777, 264, device=dev).to(torch.bfloat16)
     a = (torch.randn(777, 264, device=dev) * 3).to(torch.bfloat16)
     g = torch.randn(777, 264, device=dev).to(torch.bfloat16)
-    rm.set_precision("bf16")
-    try:
+    with rm.precision("bf16"):
         x1, a1 = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
         out = rm.gate_rows(x1, a1)
         out.backward(g)
-    finally:
-        rm.set_precision("fp32")
     x2, a2 = x.float().requires_grad_(True), a.float().requires_grad_(True)
     ref = x2 * torch.sigmoid(a2)
     ref.backward(g.float())
@@ -598,8 +611,7 @@ def test_eval_operand_cache_is_transparent_and_invalidated_by_updates():
     update must be picked up (version counters), as must a fresh module at the same address."""
     from pointcloud_bridge_amd import rowmlp
     from pointcloud_bridge_amd.models.containers import PointNet2MSG
-    rowmlp.set_precision("bf16")
-    try:
+    with rowmlp.precision("bf16"):
         torch.manual_seed(1)
         g = torch.Generator().manual_seed(3)
         v = torch.randn(2, 2048, 3, generator=g)
@@ -624,8 +636,6 @@ def test_eval_operand_cache_is_transparent_and_invalidated_by_updates():
         rowmlp._eval_operands.clear()
         d = run()               # the same weights prepared afresh
         assert torch.equal(c, d)
-    finally:
-        rowmlp.set_precision("fp32")
 
 
 def test_training_with_side_stream_prefetch_equals_training_without():
@@ -636,8 +646,7 @@ def test_training_with_side_stream_prefetch_equals_training_without():
     the same amount)."""
     from pointcloud_bridge_amd import rowmlp
     from pointcloud_bridge_amd.models.containers import PointNet2MSG
-    rowmlp.set_precision("bf16")
-    try:
+    with rowmlp.precision("bf16"):
         g = torch.Generator().manual_seed(4)
         batches = []
         for _ in range(2):
@@ -674,5 +683,3 @@ def test_training_with_side_stream_prefetch_equals_training_without():
         for a, r, b in zip(ga, gr, gb):
             noise = float((a - r).norm() / a.norm())
             assert float((a - b).norm() / a.norm()) <= 3 * noise + 1e-4, noise
-    finally:
-        rowmlp.set_precision("fp32")

@@ -220,8 +220,7 @@ def test_pipelined_inference_gives_identical_results(mpu):
     xyz2 = (xyz * 0.9).contiguous()
     model = build(PointNet2MSG, g["init_seed"], 5).eval()
     for mode in ("fp32", "bf16"):
-        rowmlp.set_precision(mode)
-        try:
+        with rowmlp.precision(mode):
             xyz3 = (xyz * 0.8).contiguous()
             with torch.no_grad():
                 torch.manual_seed(11)
@@ -233,8 +232,6 @@ def test_pipelined_inference_gives_identical_results(mpu):
                         model.set_next(nxt)  # first pass: started behind its encoder; second: at its top
                     piped.append(model(cur, colors))
             assert all(torch.equal(a, b) for a, b in zip(plain, piped)), mode
-        finally:
-            rowmlp.set_precision("fp32")
 
 
 def test_flat_adam_equals_torch_fused_adam():

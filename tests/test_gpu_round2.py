@@ -111,11 +111,8 @@ def _bf16_errors(name, kw):
     kw = dict(kw)
     cls = getattr(containers, kw.pop("cls"))
     model = build(cls, g["init_seed"], 5, **kw)
-    rowmlp.set_precision("bf16")
-    try:
+    with rowmlp.precision("bf16"):
         le, lt, loss = run_seg(model, dev(g["xyz"]), dev(g["colors"]), dev(g["labels"]), int(g["fwd_seed"]), 1)
-    finally:
-        rowmlp.set_precision("fp32")
     out = {}
     for tag, got, ref in (("eval", le, g["logits_eval"]), ("train", lt, g["logits_train"])):
         d = np.abs(got.float().detach().cpu().numpy() - ref)
@@ -163,8 +160,7 @@ def test_dgcnn_captured_step_equals_eager_step(precision, tol):
     g = load_golden("model_dgcnn")
     xyz, colors, labels = dev(g["xyz"]), dev(g["colors"]), dev(g["labels"])
     model = build(DGCNN, g["init_seed"], 5, k=20).train()
-    rowmlp.set_precision(precision)
-    try:
+    with rowmlp.precision(precision):
         def step():
             loss = F.cross_entropy(model(xyz, colors).reshape(-1, 5), labels.reshape(-1))
             loss.backward()
@@ -201,8 +197,6 @@ def test_dgcnn_captured_step_equals_eager_step(precision, tol):
                 assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-2 * gmax), replay
             junk = [torch.randn(257, 1031, device="cuda") for _ in range(8)]  # more churn: fresh blocks, written
             del junk
-    finally:
-        rowmlp.set_precision("fp32")
 
 
 def test_eval_cache_sees_flat_adam_steps_and_running_stat_updates():
@@ -228,8 +222,7 @@ def test_eval_cache_sees_flat_adam_steps_and_running_stat_updates():
             return model(xyz, col).float().clone()
 
     for precision in ("bf16", "fp32"):
-        rowmlp.set_precision(precision)
-        try:
+        with rowmlp.precision(precision):
             first = evaluate()
             assert torch.equal(first, evaluate())           # cached operands: identical
             model.train()
@@ -242,8 +235,6 @@ def test_eval_cache_sees_flat_adam_steps_and_running_stat_updates():
             assert not torch.equal(first, after), "eval output unchanged after a training step: stale cache"
             rowmlp._eval_operands.clear()
             assert torch.equal(after, evaluate()), "cached eval differs from a freshly prepared one"
-        finally:
-            rowmlp.set_precision("fp32")
 
 
 def test_prefetch_is_not_inherited_by_a_new_tensor_at_the_same_address():
@@ -352,8 +343,7 @@ def test_repeat_concat_equals_expand_cat(precision):
     expand + torch.cat: forward bit-exact; backward = the block of the gradient summed over the repeats in fp32
     (bf16 rows: within one rounding of the fp32 sum)."""
     from pointcloud_bridge_amd import rowmlp
-    rowmlp.set_precision(precision)
-    try:
+    with rowmlp.precision(precision):
         m = rowmlp.mode()
         torch.manual_seed(5)
         B, n = 3, 64
@@ -372,8 +362,6 @@ def test_repeat_concat_equals_expand_cat(precision):
             assert t.grad.shape == r.grad.shape
             err = (t.grad.float() - r.grad).abs().max() / r.grad.abs().max()
             assert err < tol, err
-    finally:
-        rowmlp.set_precision("fp32")
 
 
 @pytest.mark.gpu
@@ -529,8 +517,7 @@ def test_bf16_conv_rows_bias_gradient_from_the_weight_gradient_pass(R, K, n, gap
     """A conv without BatchNorm in bf16 mode: dbias comes out of pcb_gemm_tn_bias_bf16 (column sums of dy kept per
     row split beside the dW slabs) -- against fp32 torch on the same bf16 operands: outputs, dx, dW, dbias."""
     from pointcloud_bridge_amd import rowmlp
-    rowmlp.set_precision("bf16")
-    try:
+    with rowmlp.precision("bf16"):
         torch.manual_seed(R + n)
         conv = torch.nn.Conv1d(K, n, 1).cuda()
         x = torch.randn(R, K, device="cuda").to(torch.bfloat16).requires_grad_(True)
@@ -551,5 +538,3 @@ def test_bf16_conv_rows_bias_gradient_from_the_weight_gradient_pass(R, K, n, gap
         assert rel(x.grad, xr.grad) < 1e-2
         assert rel(conv.weight.grad.view(n, K), w.grad) < 2e-3
         assert rel(conv.bias.grad, b.grad) < 1e-4     # fp32 sums of the bf16 dy: only the summation order differs
-    finally:
-        rowmlp.set_precision("fp32")

@@ -132,11 +132,8 @@ def test_pad_rows(sfx, dtype, kp):
     """Raw fp32 coordinate / colour columns as a padded operand of the row type: equal to cast + F.pad."""
     from pointcloud_bridge_amd import rowmlp
     x = torch.randn(5000, 6, device="cuda")[:, :3]  # rows 6 floats apart
-    rowmlp.set_precision("bf16" if sfx == "bf16" else "fp32")
-    try:
+    with rowmlp.precision("bf16" if sfx == "bf16" else "fp32"):
         got = rowmlp._rows(x, kp, rowmlp.mode())
-    finally:
-        rowmlp.set_precision("fp32")
     want = F.pad(x.to(dtype), (0, kp - 3))
     assert got.dtype == dtype and torch.equal(got, want)
 
@@ -333,8 +330,7 @@ def test_conv_rows_with_the_other_branch_added_in_the_epilogue():
     (EnhancedFeaturePropagation: trunk + boundary term, reference :296).  Equal to the separate addition, gradients
     included (d/d(add) is the identity)."""
     from pointcloud_bridge_amd import rowmlp
-    rowmlp.set_precision("bf16")
-    try:
+    with rowmlp.precision("bf16"):
         torch.manual_seed(12)
         conv = torch.nn.Conv1d(64, 128, 1).cuda()
         x = torch.randn(5000, 64, device="cuda").to(torch.bfloat16).requires_grad_(True)
@@ -349,8 +345,6 @@ def test_conv_rows_with_the_other_branch_added_in_the_epilogue():
         assert torch.equal(got[0], ref.detach())          # bf16(bf16(x W^T + b) + y) both ways
         assert torch.equal(got[1], x.grad) and torch.equal(got[2], y.grad) and torch.equal(got[2], g)
         assert torch.equal(got[3], conv.weight.grad) and torch.equal(got[4], conv.bias.grad)
-    finally:
-        rowmlp.set_precision("fp32")
 
 
 @pytest.mark.parametrize("two", [True, False])
@@ -414,8 +408,7 @@ def test_conv_over_repeated_levels_equals_the_concatenated_form(train):
     conv + BatchNorm, models/model.py:150-170, :93-99, without the concatenated rows) against the same layer on
     repeat_concat's rows: output, running statistics and every gradient."""
     from pointcloud_bridge_amd import rowmlp
-    rowmlp.set_precision("bf16")
-    try:
+    with rowmlp.precision("bf16"):
         torch.manual_seed(21)
         R, reps, widths = 4096, [32, 16, 1], [128, 64, 128]
         conv = torch.nn.Conv1d(sum(widths), 128, 1).cuda()
@@ -446,8 +439,6 @@ def test_conv_over_repeated_levels_equals_the_concatenated_form(train):
         assert torch.allclose(bn.running_mean, ref_bn.running_mean, rtol=1e-3, atol=1e-3)
         assert torch.allclose(bn.running_var, ref_bn.running_var, rtol=1e-3, atol=1e-3)
         # fp32 rows: the concatenated form runs (no fused variant), same call
-        rowmlp.set_precision("fp32")
-        out32 = rowmlp.conv_bn_act_levels(conv, bn, [t.detach().float() for t in levels], reps)
+        with rowmlp.precision("fp32"):
+            out32 = rowmlp.conv_bn_act_levels(conv, bn, [t.detach().float() for t in levels], reps)
         assert out32.dtype == torch.float32 and out32.shape == (R, 128)
-    finally:
-        rowmlp.set_precision("fp32")

@@ -1,0 +1,172 @@
+"""GPU: round-3 cases around the engine's state.
+
+  * precision is scoped (rowmlp.precision context, rowmlp.bind_precision per module): two networks of different row
+    types interleave in one process and each gives the bits it gives alone
+  * a model's operand set is its own (rowmlp.attach_step_operands): preparing, training or dropping another model
+    does not touch the tables and buffers a captured step of the first one replays from
+"""
+import gc
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(seed, B=2, N=2048):
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(B, N, 3, generator=g)
+    xyz = (v / v.norm(dim=-1, keepdim=True) * torch.rand(B, N, 1, generator=g) ** (1 / 3)).cuda()
+    return xyz, torch.rand(B, N, 3, generator=g).cuda(), torch.randint(0, 5, (B, N), generator=g).cuda()
+
+
+def _model(seed):
+    from pointcloud_bridge_amd.models.containers import PointNet2MSG
+    torch.manual_seed(seed)
+    m = PointNet2MSG(5).cuda().train()
+    for s in m.modules():
+        if isinstance(s, torch.nn.Dropout):
+            s.p = 0.0
+    return m
+
+
+def _steps(model, batches, fps_seed):
+    """Two SGD steps; returns the logits and flat gradients of each."""
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    out = []
+    for i, (xyz, col, lab) in enumerate(batches):
+        opt.zero_grad(set_to_none=True)
+        torch.manual_seed(fps_seed + i)
+        logits = model(xyz, col)
+        F.cross_entropy(logits, lab).backward()
+        out.append((logits.detach().clone(), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()))
+        opt.step()
+    return out
+
+
+def test_two_precisions_interleaved_in_one_process():
+    """A bf16-bound and an fp32-bound PointNet++ MSG network take turns, step by step, inside a scope that asks for yet
+    another default; each must produce exactly what it produces when it runs alone (reproducible mode, so 'exactly'
+    means bit for bit).  Also: a stage bound to fp32 inside a bf16 network really runs in fp32 rows."""
+    from pointcloud_bridge_amd import ops, rowmlp
+    old = ops.set_deterministic(True)
+    try:
+        batches = [_batch(1), _batch(2)]
+        alone = {}
+        for prec in ("bf16", "fp32"):
+            m = rowmlp.bind_precision(_model(7), prec)
+            alone[prec] = _steps(m, batches, 100)
+        a = rowmlp.bind_precision(_model(7), "bf16")
+        b = rowmlp.bind_precision(_model(7), "fp32")
+        oa, ob = torch.optim.SGD(a.parameters(), lr=1e-2), torch.optim.SGD(b.parameters(), lr=1e-2)
+        got = {"bf16": [], "fp32": []}
+        for i, (xyz, col, lab) in enumerate(batches):
+            # (the enclosing scope's choice must not leak into either bound module -- nor theirs out of them)
+            with rowmlp.precision("fp32" if i else "bf16"):
+                for prec, net, opt in (("bf16", a, oa), ("fp32", b, ob)):
+                    opt.zero_grad(set_to_none=True)
+                    torch.manual_seed(100 + i)
+                    logits = net(xyz, col)
+                    assert rowmlp.get_precision() == ("fp32" if i else "bf16")
+                    assert logits.dtype == torch.float32
+                    F.cross_entropy(logits, lab).backward()
+                    got[prec].append((logits.detach().clone(), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()))
+                    opt.step()
+        for prec in ("bf16", "fp32"):
+            for (l1, g1), (l2, g2) in zip(alone[prec], got[prec]):
+                assert torch.equal(l1, l2) and torch.equal(g1, g2), prec
+        assert not torch.equal(alone["bf16"][0][0], alone["fp32"][0][0])     # (they are different arithmetic)
+        # mixed: the first stage in fp32 rows inside a bf16 network -- the logits move towards the fp32 network's
+        mixed = rowmlp.bind_precision(_model(7), "bf16")
+        rowmlp.bind_precision(mixed.sa1, "fp32")
+        lm = _steps(mixed, batches[:1], 100)[0][0]
+        d_mixed = float((lm - alone["fp32"][0][0]).abs().mean())
+        d_bf16 = float((alone["bf16"][0][0] - alone["fp32"][0][0]).abs().mean())
+        print("mean |logits - fp32 logits|: bf16", d_bf16, "bf16 with sa1 in fp32 rows", d_mixed)
+        assert d_mixed < 0.8 * d_bf16
+    finally:
+        ops.set_deterministic(old)
+
+
+def test_a_captured_step_survives_other_models_and_their_operand_sets():
+    """the operand tables / buffers a captured training step replays from belong to its model's own
+    StepOperands.  Capture a step of model A; then register, train, prepare and DROP a model B (and churn the
+    allocator); A's replays must keep giving what an eager step of A gives."""
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models.DGCNN import DGCNN
+    xyz, col, lab = _batch(3, N=1024)
+
+    def _model(seed):   # DGCNN: its step captures as it is (PointNet++ draws FPS start indices on the host: StaticSampling)
+        torch.manual_seed(seed)
+        return DGCNN(5, k=16).cuda().train()
+
+    with rowmlp.precision("bf16"):
+        a = _model(11)
+        ops_a = rowmlp.attach_step_operands(a)
+        assert rowmlp.attach_step_operands(a) is ops_a
+
+        def step(net):
+            loss = F.cross_entropy(net(xyz, col).reshape(-1, 5), lab.reshape(-1))
+            loss.backward()
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                      # warm-up: stacks register, centres settle, operands get prepared
+                a.zero_grad(set_to_none=True)
+                torch.manual_seed(5)
+                rowmlp.prepare_step(a)
+                step(a)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert len(ops_a.entries) >= 4 and ops_a.tables is not None
+        hits = ops_a.stats[0]
+        a.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        rowmlp.prepare_step(a)
+        eager_loss = float(step(a))
+        assert ops_a.stats[0] - hits >= 4           # the stacks found their operands prepared by the table launch
+        eager = [p.grad.clone() for p in a.parameters()]
+        for p in a.parameters():
+            p.grad = None
+        loss_buf = torch.zeros((), device="cuda")
+        graph = torch.cuda.CUDAGraph()
+        torch.manual_seed(5)
+        with torch.cuda.graph(graph):
+            rowmlp.prepare_step(a)
+            loss_buf.copy_(step(a).detach())
+        tables_before = {k: t[0].data_ptr() for k, t in ops_a.tables.items()}
+
+        def check(tag):
+            for p in a.parameters():
+                p.grad.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert abs(float(loss_buf) - eager_loss) < 2e-3 * abs(eager_loss), tag
+            gmax = max(float(t.abs().max()) for t in eager)
+            for got, want in zip([p.grad for p in a.parameters()], eager):
+                assert float((got - want).abs().max()) <= 0.1 * max(float(want.abs().max()), 1e-2 * gmax), tag
+
+        check("first replay")
+        # another model with its own set, and one in the process default set: trained, prepared, dropped
+        for own in (True, False):
+            b = _model(12)
+            if own:
+                rowmlp.attach_step_operands(b)
+            opt = torch.optim.SGD(b.parameters(), lr=1e-2)
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                torch.manual_seed(6)
+                step(b)
+                opt.step()
+                rowmlp.prepare_step(b if own else None)
+            del b, opt
+            gc.collect()
+            torch.cuda.empty_cache()
+            junk = [torch.randn(1 << 20, device="cuda") for _ in range(8)]
+            del junk
+            rowmlp.prepare_step(None)               # the default set prunes its dead entries: nothing of A's moves
+            assert {k: t[0].data_ptr() for k, t in ops_a.tables.items()} == tables_before
+            check("after another model, own set = %s" % own)
