@@ -460,6 +460,25 @@ int pcb_prep_linear_bias_bf16(const float *w, const float *bias, int n, int k, i
 int pcb_prep_linear_bias_f32(const float *w, const float *bias, int n, int k, int npad, int kp, int gap,
                              void *wp, void *wt, float *bp, void *stream);
 
+/*
+ * One layer's backward in ONE pass (bf16 rows): what pcb_gemm_nt_red_bf16 + pcb_gemm_tn_bf16 compute for layer l >= 1 of a
+ * stack -- the reference's autograd of Conv(1x1) -> BatchNorm -> ReLU (models/pointnet2_utils.py:149-154, :353-356) -- for
+ * the narrow layers that carry most rows (C, K multiples of 8, at most 128: pcb_bwd_fused_supported):
+ *   dx [R,K] bf16 = dy . W                       (= dz of the layer below)
+ *   dW [C, out_cols] = dy^T . x'                 (nparts slabs [C*K] in `workspace`, summed in slab order; weight layout
+ *                                                 and out_cols / out_perm as pcb_gemm_tn_bf16)
+ *   red_sums [nparts][2][K] = the layer below's BatchNorm-backward sums (as pcb_gemm_nt_red_bf16)
+ * dy = BatchNorm/activation backward of this layer from (dz, y) (pro 2) or (dout, argmax, y) (pro 3) with scale, shift,
+ * p, q; x' = act(x*xscale + xshift) from the layer below's raw rows x [R,K] and its constants; wt [K,C] = the prepared
+ * transposed weight.  (dz, y) and x stream from HBM once instead of twice.  The launch runs exactly nparts workgroups.
+ */
+int pcb_bwd_fused_supported(int C, int K);
+int pcb_bwd_fused_bf16(int pro, const void *dz, const void *y, const float *scale, const float *shift, const float *p,
+                       const float *q, const float *dout, const unsigned char *argmax, int ns, int act, const void *wt,
+                       const void *x, const float *xscale, const float *xshift, const float *xmean, const float *xinvstd,
+                       int xact, long R, int C, int K, void *dx, float *red_sums, int nparts, float *workspace, float *dW,
+                       int out_cols, int out_perm, void *stream);
+
 /* Tell the library that another kernel occupies about `busy_cus` compute units beside the launches
  * that follow (e.g. the next batch's FPS on a side stream during the backward pass): the persistent
  * GEMMs without slabs, the weight-gradient splits and the slab-count recommendation then leave

@@ -118,6 +118,9 @@ SIGNATURES = {
     "pcb_timer_enable": [_i],
     "pcb_timer_stop": [_p, _p, _p],
     "pcb_timer_read": [_i, _p, _p, _p],
+    "pcb_bwd_fused_supported": [_i, _i],
+    "pcb_bwd_fused_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _p, _i, _p, _p,
+                           _i, _i, _p],
     "pcb_gemm_nt_red_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     "pcb_gemm_nt_red_f32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     "pcb_bn_act_bwd_reduce_bf16": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _i, _p],

@@ -1195,6 +1195,235 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kerne
     }
 }
 
+// ---- one layer's backward in ONE pass: input gradient + weight gradient + the sums of the layer below ----------------
+// The backward of layer l of a stack is two GEMMs over the same operand: dx = dy W (gemm_nt with the dy prologue and the
+// RED epilogue) and dW = dy^T x' (gemm_tn with the same prologue).  Run as two kernels, (dz, y) of the layer stream from HBM
+// twice, y of the layer below twice as well (x' for dW, the RED epilogue), and the 15 vector instructions per MFMA of the dy
+// prologue are paid twice.  For the NARROW layers that carry most of the step's rows (the set-abstraction stacks: C, K <= 128
+// over 131072 .. 524288 rows) everything fits one workgroup: a 64-row tile of dy [64, C] and of x' [64, K] in LDS, the
+// transposed weight [K, C] resident in LDS for the workgroup's life, accumulators for the whole dW [C, K] (64 registers per
+// lane at 128 x 128) and for the tile's dx [64, K] (32).  Per row tile:
+//     park    dy = prologue(dz | dout+argmax, y), x' = act(y_below * scale + shift)  -> LDS       (loads issued a tile ahead)
+//     dW     += dy^T x'        both operands by transposed LDS reads (ds_read_b64_tr_b16), as gemm_tn
+//     dx      = dy W           A rows from the dy tile, B rows from the resident W^T, as gemm_nt
+//     store   dx as bf16 row segments (= dz of the layer below) + ITS BatchNorm-backward sums from (dx, y_below)
+// HBM bytes per row: 2C (+2C for a dense dz) + 2K read, 2K written -- against 8C + 6K (dense) for the two-kernel form.
+// Persistent over row tiles; every workgroup writes ONE dW slab (summed in slab order by pcb_reduce_slabs, as gemm_tn's) and
+// one slab of the sums (pcb_bn_bwd_finalize adds them).  No atomics: reproducible.
+constexpr int BF_BM = 64;
+
+template <int APRO, int TC, int TK>
+__global__ __launch_bounds__(256, 2) void bwd_fused_kernel(Operand A_arg, Operand X_arg, const u16 *__restrict__ Wt, long R, int C,
+                                                           int K, u16 *__restrict__ dx, RedArgs red_arg, float *__restrict__ red_sums,
+                                                           float *__restrict__ part)
+{
+    static_assert(APRO == PRO_DY || APRO == PRO_DY_POOL, "a BatchNorm-backward prologue");
+    const Operand A = local_copy(A_arg);
+    const Operand X = local_copy(X_arg);
+    const float a_slope = act_slope(A.act), x_slope = act_slope(X.act), red_slope = act_slope(red_arg.act);
+    constexpr int LDC = TC + 32, LDK = TK + 32;     // row strides of the dy / x' tiles (bf16): conflict-free transposed reads
+    constexpr int LDW = TC + 8;                      // row stride of the resident W^T [TK][TC]
+    constexpr int LDS_ = TK + 8;                     // dx staging rows (in the x' tile's buffer)
+    constexpr int CHC = TC / 8, CHK = TK / 8;        // 16-byte chunks per tile row
+    constexpr int RPC = 256 / CHC, RPK = 256 / CHK;  // rows one pass of the 256 threads covers
+    constexpr int NC = BF_BM / RPC, NK = BF_BM / RPK;  // chunks per thread and tile
+    constexpr int XA = TC / 64, XB = TK / 64;        // 32-wide MFMA tiles per wave of dW (2 x 2 waves: TC/2 x TK/2 each)
+    static_assert(BF_BM * LDS_ <= BF_BM * LDK, "the dx staging rows live in the x' tile");
+    __shared__ __attribute__((aligned(16))) u16 smem[BF_BM * LDC + BF_BM * LDK + TK * LDW];   // 78 KB at 128 x 128: two per CU
+    u16 *const Dy = smem;
+    u16 *const Xs = smem + BF_BM * LDC;
+    u16 *const Ws = Xs + BF_BM * LDK;
+    __shared__ __attribute__((aligned(16))) float cstA[4 * TC];   // scale | shift | p | q of this layer
+    __shared__ __attribute__((aligned(16))) float cstX[4 * TK];   // scale | shift | mean | invstd of the layer below
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long tiles = (R + BF_BM - 1) / BF_BM;
+
+    // once per workgroup: constants and W^T (rows = input columns k, contraction index c contiguous; zero outside [K, C])
+    for (int i = t; i < TC; i += 256) {
+        const bool ok = i < C;
+        cstA[i] = ok ? A.scale[i] : 0.0f;
+        cstA[TC + i] = ok ? A.shift[i] : 0.0f;
+        cstA[2 * TC + i] = ok ? A.p[i] : 0.0f;
+        cstA[3 * TC + i] = ok ? A.q[i] : 0.0f;
+    }
+    for (int i = t; i < TK; i += 256) {
+        const bool ok = i < K;
+        cstX[i] = ok ? X.scale[i] : 0.0f;
+        cstX[TK + i] = ok ? X.shift[i] : 0.0f;
+        cstX[2 * TK + i] = ok ? red_arg.mean[i] : 0.0f;
+        cstX[3 * TK + i] = ok ? red_arg.invstd[i] : 0.0f;
+    }
+    for (int i = t; i < TK * CHC; i += 256) {
+        const int n = i / CHC, c8 = (i % CHC) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (n < K && c8 < C) v = *reinterpret_cast<const uint4 *>(Wt + (long)n * C + c8);
+        *reinterpret_cast<uint4 *>(&Ws[n * LDW + c8]) = v;
+    }
+
+    f32x16 accw[XA][XB];
+#pragma unroll
+    for (int a = 0; a < XA; ++a)
+#pragma unroll
+        for (int b = 0; b < XB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accw[a][b][i] = 0.0f;
+
+    const int chc = t % CHC, rowc = t / CHC;   // this thread's column chunk / first row of the dy tile
+    const int chk = t % CHK, rowk = t / CHK;   // ... of the x' tile (and of the dx rows it stores)
+    Raw<APRO> ra[NC];
+    Raw<PRO_BNACT> rx[NK];
+    auto fetch = [&](long tile) {
+        const long m0 = tile * BF_BM;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) ra[i].load(A, m0 + rowc + RPC * i, chc * 8, R, C);
+#pragma unroll
+        for (int i = 0; i < NK; ++i) rx[i].load(X, m0 + rowk + RPK * i, chk * 8, R, K);
+    };
+    const int grp = lane >> 4, gi = lane & 15;
+    const int tr_row = 8 * (grp >> 1) + (gi >> 2);
+    const int tr_col = 16 * (grp & 1) + 4 * (gi & 3);
+    float rs1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rs2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sums of this thread's 8 dx columns
+
+    long tile = blockIdx.x;
+    if (tile < tiles) fetch(tile);
+    __syncthreads();  // constants, W^T
+    for (; tile < tiles; tile += gridDim.x) {
+        const long m0 = tile * BF_BM;
+        {   // park: both tiles, transformed
+            ConstsLds<APRO> ka;
+            ka.load(cstA, TC, chc * 8);
+            ConstsLds<PRO_BNACT> kx;
+            kx.load(cstX, TK, chk * 8);
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                *reinterpret_cast<uint4 *>(&Dy[(rowc + RPC * i) * LDC + chc * 8]) = finish_with<APRO>(ra[i], ka, a_slope);
+#pragma unroll
+            for (int i = 0; i < NK; ++i)
+                *reinterpret_cast<uint4 *>(&Xs[(rowk + RPK * i) * LDK + chk * 8]) = finish_with<PRO_BNACT>(rx[i], kx, x_slope);
+        }
+        __syncthreads();
+        if (tile + gridDim.x < tiles) fetch(tile + gridDim.x);   // the next tile's loads fly under everything below
+        // dW += dy^T x'   (contraction over the tile's 64 rows)
+        typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+#pragma unroll
+        for (int ks = 0; ks < BF_BM / 16; ++ks) {
+            bf16x8 af[XA], bf[XB];
+#pragma unroll
+            for (int x = 0; x < XA; ++x) {
+                const u16 *pa = &Dy[(ks * 16 + tr_row) * LDC + wm * (TC / 2) + x * 32 + tr_col];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pa);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pa + 4 * LDC));
+                af[x] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int x = 0; x < XB; ++x) {
+                const u16 *pb = &Xs[(ks * 16 + tr_row) * LDK + wn * (TK / 2) + x * 32 + tr_col];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pb);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pb + 4 * LDK));
+                bf[x] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int a = 0; a < XA; ++a)
+#pragma unroll
+                for (int b = 0; b < XB; ++b)
+                    accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], accw[a][b], 0, 0, 0);
+        }
+        // dx = dy W   (2 x 2 waves: 32 rows x TK/2 columns each)
+        f32x16 accx[XB];
+#pragma unroll
+        for (int j = 0; j < XB; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accx[j][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < TC / 16; ++ks) {
+            const int kk = ks * 16 + (lane >> 5) * 8;
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Dy[(wm * 32 + (lane & 31)) * LDC + kk]);
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[(wn * (TK / 2) + j * 32 + (lane & 31)) * LDW + kk]);
+                accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, accx[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // every wave is through with the x' tile: its buffer takes the dx rows
+        u16 *const St = Xs;
+#pragma unroll
+        for (int j = 0; j < XB; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                St[(wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * LDS_ + wn * (TK / 2) + j * 32 + (lane & 31)] = f2bf(accx[j][i]);
+        __syncthreads();
+        // store dx (= dz of the layer below) as 16-byte row segments and add its BatchNorm-backward sums: this thread owns
+        // the same (row, chunk) positions it loaded y_below at -- the raw rows are requested again (L2: they were read a
+        // moment ago) rather than kept in registers across the MFMA phases
+        {
+            uint4 yraw[NK];
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const long r = m0 + rowk + RPK * i;
+                yraw[i] = *reinterpret_cast<const uint4 *>(X.a0 + (r < R ? r : R - 1) * X.ld + (chk * 8 < K ? chk * 8 : 0));
+            }
+            float sc[8], sh[8], mu[8], is[8];
+            ConstsLds<PRO_BNACT>::rd8(cstX + chk * 8, sc);
+            ConstsLds<PRO_BNACT>::rd8(cstX + TK + chk * 8, sh);
+            ConstsLds<PRO_BNACT>::rd8(cstX + 2 * TK + chk * 8, mu);
+            ConstsLds<PRO_BNACT>::rd8(cstX + 3 * TK + chk * 8, is);
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int rr = rowk + RPK * i;
+                const long r = m0 + rr;
+                const uint4 o = *reinterpret_cast<const uint4 *>(&St[rr * LDS_ + chk * 8]);
+                if (r < R && chk * 8 < K) {
+                    *reinterpret_cast<uint4 *>(dx + r * K + chk * 8) = o;
+                    float dzv[8], yv[8];
+                    unpack8(o, dzv);
+                    unpack8(yraw[i], yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float du = dzv[e] * act_grad(fmaf(yv[e], sc[e], sh[e]), red_slope);
+                        rs1[e] += du;
+                        rs2[e] = fmaf(du, (yv[e] - mu[e]) * is[e], rs2[e]);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the staging rows and the dy tile are rebuilt by the next park
+    }
+
+    // the sums of the layer below: threads sharing a column chunk (same t % CHK) meet in LDS, fixed order
+    {
+        float *const red = reinterpret_cast<float *>(smem);   // [RPK][2][TK] floats over the (idle) dy and x' tiles
+        static_assert(RPK * 2 * TK * 4 <= (BF_BM * LDC + BF_BM * LDK) * 2, "the reduction scratch must fit the two tiles");
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(rowk * 2 + 0) * TK + chk * 8 + e] = rs1[e];
+            red[(rowk * 2 + 1) * TK + chk * 8 + e] = rs2[e];
+        }
+        __syncthreads();
+        for (int o = t; o < 2 * TK; o += 256) {
+            const int m = o / TK, c = o % TK;
+            float a = 0.0f;
+            for (int r = 0; r < RPK; ++r) a += red[(r * 2 + m) * TK + c];
+            if (c < K) red_sums[((long)blockIdx.x * 2 + m) * K + c] = a;
+        }
+    }
+    // this workgroup's dW slab (workgroups without a tile write zeros: every slab is summed)
+#pragma unroll
+    for (int a = 0; a < XA; ++a)
+#pragma unroll
+        for (int b = 0; b < XB; ++b) {
+            const int n = wn * (TK / 2) + b * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = wm * (TC / 2) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (m < C && n < K) part[(long)blockIdx.x * C * K + (long)m * K + n] = accw[a][b][i];
+            }
+        }
+}
+
 // dy = scale*du + p*y + q written out as rows (the PRO_DY prologue as a pass of its own), for the layers whose
 // gradient GEMMs would otherwise rebuild it once per 128-column tile of a WIDE partner matrix: the input-gradient
 // GEMM of a layer with K = C > 256 (too wide for the A-resident kernel) and N > 256 inputs walks >= 3 column tiles,
@@ -1620,6 +1849,61 @@ extern "C" int pcb_gemm_tn_bias_bf16(const void *dy, const void *x, long R, int 
     launch_tn<PRO_PLAIN>(A, B, PRO_PLAIN, R, M, N, workspace, dW, out_cols, out_perm, (hipStream_t)stream, dbias);
     pcb_account(2.0 * R * M + 2.0 * R * N);
     return pcb_check_launch();
+}
+
+// One layer's backward in one pass (bwd_fused_kernel): dx [R,K] = dy . W (bf16, = dz of the layer below), dW = dy^T . x' as
+// `nparts` slabs [C*K] in `workspace` summed into dW [C, out_cols] (weight layout, as pcb_gemm_tn_bf16), and the layer
+// below's BatchNorm-backward sums as `nparts` slabs red_sums [nparts][2][K].  dy from (dz | dout + argmax, y) with
+// scale / shift / p / q (pro 2 / 3 as pcb_gemm_nt_bf16); x' = act(x * xscale + xshift) with the layer below's raw rows x
+// (= red_y: the same tensor) and its mean / invstd.  wt = the layer's prepared transposed weight [K, C].
+// C, K multiples of 8, at most 128; 1 <= nparts <= PCB_MAX_SLABS (the grid).
+extern "C" int pcb_bwd_fused_supported(int C, int K) { return C > 0 && K > 0 && !(C & 7) && !(K & 7) && C <= 128 && K <= 128; }
+
+extern "C" int pcb_bwd_fused_bf16(int pro, const void *dz, const void *y, const float *scale, const float *shift, const float *p,
+                                  const float *q, const float *dout, const unsigned char *argmax, int ns, int act,
+                                  const void *wt, const void *x, const float *xscale, const float *xshift,
+                                  const float *xmean, const float *xinvstd, int xact, long R, int C, int K, void *dx,
+                                  float *red_sums, int nparts, float *workspace, float *dW, int out_cols, int out_perm,
+                                  void *stream)
+{
+    if (!y || !scale || !shift || !p || !q || !wt || !x || !xscale || !xshift || !xmean || !xinvstd || !dx || !red_sums ||
+        !workspace || !dW || R <= 0)
+        return PCB_ERR_INVALID_ARG;
+    if (pro != PRO_DY && pro != PRO_DY_POOL) return PCB_ERR_INVALID_ARG;
+    if (pro == PRO_DY ? !dz : (!dout || !argmax || ns <= 0 || ns > 255)) return PCB_ERR_INVALID_ARG;
+    if (!pcb_bwd_fused_supported(C, K)) return PCB_ERR_UNSUPPORTED;
+    if (nparts < 1 || nparts > PCB_MAX_SLABS) return PCB_ERR_INVALID_ARG;
+    if (out_cols <= 0) { out_cols = K; out_perm = 0; }
+    if (out_cols > K) return PCB_ERR_INVALID_ARG;
+    const Operand A = make_operand(dz, y, C, scale, shift, p, q, dout, argmax, ns, act);
+    const Operand X = make_operand(x, nullptr, K, xscale, xshift, nullptr, nullptr, nullptr, nullptr, 1, xact);
+    RedArgs red = {(const u16 *)x, xscale, xshift, xmean, xinvstd, xact, nullptr, nullptr};
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t timed;
+    pcb_timer_begin(st, &timed);
+    const dim3 grid((unsigned)nparts);
+#define PCB_BF_LAUNCH(P, TC_, TK_)                                                                                              \
+    hipLaunchKernelGGL((bwd_fused_kernel<P, TC_, TK_>), grid, dim3(256), 0, st, A, X, (const u16 *)wt, R, C, K, (u16 *)dx, red, \
+                       red_sums, workspace)
+    const bool wc = C > 64, wk = K > 64;
+    if (pro == PRO_DY) {
+        if (wc && wk) PCB_BF_LAUNCH(PRO_DY, 128, 128);
+        else if (wc) PCB_BF_LAUNCH(PRO_DY, 128, 64);
+        else if (wk) PCB_BF_LAUNCH(PRO_DY, 64, 128);
+        else PCB_BF_LAUNCH(PRO_DY, 64, 64);
+    } else {
+        if (wc && wk) PCB_BF_LAUNCH(PRO_DY_POOL, 128, 128);
+        else if (wc) PCB_BF_LAUNCH(PRO_DY_POOL, 128, 64);
+        else if (wk) PCB_BF_LAUNCH(PRO_DY_POOL, 64, 128);
+        else PCB_BF_LAUNCH(PRO_DY_POOL, 64, 64);
+    }
+#undef PCB_BF_LAUNCH
+    // algorithmic bytes: the dy operand as its prologue reads it, the rows of the layer below once, dx written once
+    const double bytes = nt_bytes(pro, R, 0, C, ns) + 2.0 * R * K + 2.0 * R * K;
+    pcb_timer_end(st, timed, bytes, pro + 20, R, K, C);
+    const int status = pcb_check_launch();
+    if (status != PCB_OK) return status;
+    return pcb_reduce_slabs(workspace, nparts, (long)C * K, dW, K, out_cols, out_perm, 8, st);
 }
 
 // pcb_gemm_nt_bf16 for an input-gradient GEMM (pro 2 or 3) that ALSO accumulates the BatchNorm

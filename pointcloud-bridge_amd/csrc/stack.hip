@@ -702,6 +702,29 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
                                                 ptr<float>(a.ext[X_DADD1]), (int)a.ext[X_SH2], ptr<float>(a.ext[X_DADD2]),
                                                 stream));
             }
+            // a narrow inner layer (C, K <= 128): input gradient, weight gradient and the sums of the layer below from ONE
+            // pass over (dz, y) and the rows below (bwd_fused_kernel) instead of gemm_tn + gemm_nt_red
+            static const bool fused_off = getenv("PCB_BWD_FUSED") && atoi(getenv("PCB_BWD_FUSED")) == 0;
+            if (!fused_off && dtype == PCB_DTYPE_BF16 && l > 0 && a.dW && parts && !side && apro >= 2 && !a.ext &&
+                pcb_bwd_fused_supported(a.C, a.kp)) {
+                const Layer &b = ly[l - 1];
+                long rps;
+                long grid = (R + 63) / 64;                                    // row tiles of the kernel
+                const long cap = 512 - 2L * busy > 64 ? 512 - 2L * busy : 64;  // two workgroups per CU it may use
+                const long slabs = pcb_tn_splits(R, a.C, a.kp, &rps, 512);     // what the caller's workspace region holds
+                grid = grid < cap ? grid : cap;
+                grid = grid < slabs ? grid : slabs;
+                grid = grid < parts_slabs ? grid : parts_slabs;
+                void *dprev = (void *)((char *)dzbuf + (size_t)(l & 1) * R * maxw * op.elem);
+                PCB_TRY(pcb_bwd_fused_bf16(apro, dz, a.y, scale, shift, p, q, dout, argmax, ns, act, wb + a.wt_off * op.elem, b.y,
+                                           row(stz, b, 2), row(stz, b, 3), row(stz, b, 4), row(stz, b, 5), act, R, a.C, a.kp,
+                                           dprev, parts, (int)grid, workspace + ws_off[l], a.dW, a.k, 0, stream));
+                have_parts = true;
+                have_nparts = (int)grid;
+                dz = dprev;
+                dout = nullptr;
+                continue;
+            }
             // weight gradient, in the parameter's own layout -- on the side stream
             hipEvent_t tn_prev = tn_done;  // gemm_tn(l+1): still reading the buffer gemm_nt(l) will write
             if (a.dW) {

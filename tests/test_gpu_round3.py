@@ -170,3 +170,58 @@ def test_a_captured_step_survives_other_models_and_their_operand_sets():
             rowmlp.prepare_step(None)               # the default set prunes its dead entries: nothing of A's moves
             assert {k: t[0].data_ptr() for k, t in ops_a.tables.items()} == tables_before
             check("after another model, own set = %s" % own)
+
+
+@pytest.mark.parametrize("pro,R,C,K,ns", [(2, 4096, 128, 128, 1), (2, 1000, 64, 64, 1), (3, 2048, 128, 64, 16), (3, 999 * 8, 64, 128, 8),
+                                          (2, 64 * 600, 72, 40, 1), (3, 70 * 32, 128, 128, 32), (2, 50, 8, 8, 1)])
+def test_fused_layer_backward_equals_the_two_kernel_form(pro, R, C, K, ns):
+    """pcb_bwd_fused_bf16 (one pass over (dz, y) and the rows below: dx, dW, the sums of the layer below) against
+    pcb_gemm_nt_red_bf16 + pcb_gemm_tn_bf16, the pair it replaces for the narrow layers: dx bit-identical (the same
+    prologue, the same MFMA order over C), dW and the sums up to the order of the fp32 additions (other row splits)."""
+    from pointcloud_bridge_amd import _lib
+    from pointcloud_bridge_amd.ops import _launch
+    L = _lib.load()
+    assert L.pcb_bwd_fused_supported(C, K) == 1 and L.pcb_bwd_fused_supported(256, 64) == 0 and L.pcb_bwd_fused_supported(60, 64) == 0
+    g = torch.Generator().manual_seed(R + C)
+    dev = torch.device("cuda")
+    y = torch.randn(R, C, generator=g).to(dev).to(torch.bfloat16)
+    x = torch.randn(R, K, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(C, K, generator=g) * 0.2).to(dev).to(torch.bfloat16)          # the layer's weight [C, K]
+    wt = w.t().contiguous()                                                        # prepared transposed copy [K, C]
+    scale, shift = torch.rand(C, generator=g).to(dev) + 0.5, torch.randn(C, generator=g).to(dev) * 0.3
+    p, q = torch.randn(C, generator=g).to(dev) * 0.05, torch.randn(C, generator=g).to(dev) * 0.05
+    xs, xh = torch.rand(K, generator=g).to(dev) + 0.5, torch.randn(K, generator=g).to(dev) * 0.3
+    xm, xi = torch.randn(K, generator=g).to(dev) * 0.1, torch.rand(K, generator=g).to(dev) + 0.5
+    if pro == 3:
+        G = R // ns
+        dout = torch.randn(G, C, generator=g).to(dev)
+        arg = torch.randint(0, ns, (G, C), generator=g).to(dev).to(torch.uint8)
+        dz = None
+    else:
+        dz = torch.randn(R, C, generator=g).to(dev).to(torch.bfloat16)
+        dout = arg = None
+    a_args = (0 if dz is None else dz.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), p.data_ptr(), q.data_ptr(),
+              0 if dout is None else dout.data_ptr(), 0 if arg is None else arg.data_ptr(), ns, 1)
+    # the two-kernel form
+    nparts = L.pcb_gemm_nt_partials(pro, R, K)
+    dx_ref = torch.full((R, K), float("nan"), dtype=torch.bfloat16, device=dev)
+    red_ref = torch.empty(nparts, 2, K, device=dev)
+    _launch("pcb_gemm_nt_red_bf16", 0, pro, *a_args, wt.data_ptr(), R, K, C, dx_ref.data_ptr(), x.data_ptr(), xs.data_ptr(),
+            xh.data_ptr(), xm.data_ptr(), xi.data_ptr(), 1, red_ref.data_ptr(), nparts)
+    ws = torch.empty(L.pcb_gemm_tn_workspace(R, C, K), device=dev)
+    dw_ref = torch.full((C, K), float("nan"), device=dev)
+    _launch("pcb_gemm_tn_bf16", 0, pro, *a_args, 1, x.data_ptr(), xs.data_ptr(), xh.data_ptr(), 1, R, C, K, ws.data_ptr(),
+            dw_ref.data_ptr(), K, 0)
+    # one pass
+    for grid in (1, 7, min(512, (R + 63) // 64)):
+        dx = torch.full((R, K), float("nan"), dtype=torch.bfloat16, device=dev)
+        red = torch.full((grid, 2, K), float("nan"), device=dev)
+        ws2 = torch.full((grid * C * K,), float("nan"), device=dev)
+        dw = torch.full((C, K), float("nan"), device=dev)
+        _launch("pcb_bwd_fused_bf16", 0, pro, *a_args, wt.data_ptr(), x.data_ptr(), xs.data_ptr(), xh.data_ptr(), xm.data_ptr(),
+                xi.data_ptr(), 1, R, C, K, dx.data_ptr(), red.data_ptr(), grid, ws2.data_ptr(), dw.data_ptr(), K, 0)
+        assert torch.equal(dx, dx_ref), grid
+        tol = 2e-3 * float(dw_ref.abs().max())
+        assert float((dw - dw_ref).abs().max()) <= tol, (grid, float((dw - dw_ref).abs().max()), tol)
+        tot, tot_ref = red.double().sum(0), red_ref.double().sum(0)
+        assert float((tot - tot_ref).abs().max()) <= 1e-4 * float(tot_ref.abs().max()) + 1e-4, grid
