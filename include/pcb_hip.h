@@ -463,7 +463,7 @@ int pcb_prep_linear_bias_f32(const float *w, const float *bias, int n, int k, in
 /*
  * One layer's backward in ONE pass (bf16 rows): what pcb_gemm_nt_red_bf16 + pcb_gemm_tn_bf16 compute for layer l >= 1 of a
  * stack -- the reference's autograd of Conv(1x1) -> BatchNorm -> ReLU (models/pointnet2_utils.py:149-154, :353-356) -- for
- * the narrow layers that carry most rows (C, K multiples of 8, at most 128: pcb_bwd_fused_supported):
+ * the narrow layers that carry most rows (C, K multiples of 8, C <= 256, K <= 128: pcb_bwd_fused_supported):
  *   dx [R,K] bf16 = dy . W                       (= dz of the layer below)
  *   dW [C, out_cols] = dy^T . x'                 (nparts slabs [C*K] in `workspace`, summed in slab order; weight layout
  *                                                 and out_cols / out_perm as pcb_gemm_tn_bf16)

@@ -1212,8 +1212,10 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void gemm_tn_kerne
 // one slab of the sums (pcb_bn_bwd_finalize adds them).  No atomics: reproducible.
 constexpr int BF_BM = 64;
 
-template <int APRO, int TC, int TK>
-__global__ __launch_bounds__(256, 2) void bwd_fused_kernel(Operand A_arg, Operand X_arg, const u16 *__restrict__ Wt, long R, int C,
+// WAVES = 4: C, K <= 128, two workgroups per CU.  WAVES = 8: C <= 256 (K <= 128) -- the last layers of the second
+// set-abstraction level -- 131 KB of LDS, one workgroup per CU, the same eight waves; dW tiled 4 x 2 over the waves, dx 2 x 4.
+template <int APRO, int TC, int TK, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void bwd_fused_kernel(Operand A_arg, Operand X_arg, const u16 *__restrict__ Wt, long R, int C,
                                                            int K, u16 *__restrict__ dx, RedArgs red_arg, float *__restrict__ red_sums,
                                                            float *__restrict__ part)
 {
@@ -1225,11 +1227,16 @@ __global__ __launch_bounds__(256, 2) void bwd_fused_kernel(Operand A_arg, Operan
     constexpr int LDW = TC + 8;                      // row stride of the resident W^T [TK][TC]
     constexpr int LDS_ = TK + 8;                     // dx staging rows (in the x' tile's buffer)
     constexpr int CHC = TC / 8, CHK = TK / 8;        // 16-byte chunks per tile row
-    constexpr int RPC = 256 / CHC, RPK = 256 / CHK;  // rows one pass of the 256 threads covers
+    constexpr int THREADS = WAVES * 64;
+    constexpr int RPC = THREADS / CHC, RPK = THREADS / CHK;  // rows one pass of the workgroup's threads covers
     constexpr int NC = BF_BM / RPC, NK = BF_BM / RPK;  // chunks per thread and tile
-    constexpr int XA = TC / 64, XB = TK / 64;        // 32-wide MFMA tiles per wave of dW (2 x 2 waves: TC/2 x TK/2 each)
+    constexpr int WMB = WAVES / 2, WNB = 2;          // dW [TC, TK] over WMB x WNB waves: (TC / WMB) x (TK / 2) each
+    constexpr int XA = TC / WMB / 32, XB = TK / WNB / 32;   // 32-wide MFMA tiles per wave of dW
+    constexpr int WNA = WAVES / 2;                   // dx [64, TK] over 2 x WNA waves: 32 rows x (TK / WNA) columns each
+    constexpr int XD = TK / WNA / 32;
+    static_assert(NC >= 1 && NK >= 1 && XA >= 1 && XB >= 1 && XD >= 1, "tile / wave decomposition");
     static_assert(BF_BM * LDS_ <= BF_BM * LDK, "the dx staging rows live in the x' tile");
-    __shared__ __attribute__((aligned(16))) u16 smem[BF_BM * LDC + BF_BM * LDK + TK * LDW];   // 78 KB at 128 x 128: two per CU
+    __shared__ __attribute__((aligned(16))) u16 smem[BF_BM * LDC + BF_BM * LDK + TK * LDW];   // 78 KB at 128 x 128: two per CU; 122 KB at 256 x 128
     u16 *const Dy = smem;
     u16 *const Xs = smem + BF_BM * LDC;
     u16 *const Ws = Xs + BF_BM * LDK;
@@ -1239,25 +1246,26 @@ __global__ __launch_bounds__(256, 2) void bwd_fused_kernel(Operand A_arg, Operan
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;       // position in the dW decomposition
+    const int wma = wave / WNA, wna = wave % WNA;  // ... in the dx decomposition
     const long tiles = (R + BF_BM - 1) / BF_BM;
 
     // once per workgroup: constants and W^T (rows = input columns k, contraction index c contiguous; zero outside [K, C])
-    for (int i = t; i < TC; i += 256) {
+    for (int i = t; i < TC; i += THREADS) {
         const bool ok = i < C;
         cstA[i] = ok ? A.scale[i] : 0.0f;
         cstA[TC + i] = ok ? A.shift[i] : 0.0f;
         cstA[2 * TC + i] = ok ? A.p[i] : 0.0f;
         cstA[3 * TC + i] = ok ? A.q[i] : 0.0f;
     }
-    for (int i = t; i < TK; i += 256) {
+    for (int i = t; i < TK; i += THREADS) {
         const bool ok = i < K;
         cstX[i] = ok ? X.scale[i] : 0.0f;
         cstX[TK + i] = ok ? X.shift[i] : 0.0f;
         cstX[2 * TK + i] = ok ? red_arg.mean[i] : 0.0f;
         cstX[3 * TK + i] = ok ? red_arg.invstd[i] : 0.0f;
     }
-    for (int i = t; i < TK * CHC; i += 256) {
+    for (int i = t; i < TK * CHC; i += THREADS) {
         const int n = i / CHC, c8 = (i % CHC) * 8;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (n < K && c8 < C) v = *reinterpret_cast<const uint4 *>(Wt + (long)n * C + c8);
@@ -1314,7 +1322,7 @@ __global__ __launch_bounds__(256, 2) void bwd_fused_kernel(Operand A_arg, Operan
             bf16x8 af[XA], bf[XB];
 #pragma unroll
             for (int x = 0; x < XA; ++x) {
-                const u16 *pa = &Dy[(ks * 16 + tr_row) * LDC + wm * (TC / 2) + x * 32 + tr_col];
+                const u16 *pa = &Dy[(ks * 16 + tr_row) * LDC + wm * (TC / WMB) + x * 32 + tr_col];
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pa);
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pa + 4 * LDC));
                 af[x] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -1332,29 +1340,29 @@ __global__ __launch_bounds__(256, 2) void bwd_fused_kernel(Operand A_arg, Operan
                 for (int b = 0; b < XB; ++b)
                     accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], accw[a][b], 0, 0, 0);
         }
-        // dx = dy W   (2 x 2 waves: 32 rows x TK/2 columns each)
-        f32x16 accx[XB];
+        // dx = dy W   (2 x WNA waves: 32 rows x TK / WNA columns each)
+        f32x16 accx[XD];
 #pragma unroll
-        for (int j = 0; j < XB; ++j)
+        for (int j = 0; j < XD; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) accx[j][i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < TC / 16; ++ks) {
             const int kk = ks * 16 + (lane >> 5) * 8;
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Dy[(wm * 32 + (lane & 31)) * LDC + kk]);
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Dy[(wma * 32 + (lane & 31)) * LDC + kk]);
 #pragma unroll
-            for (int j = 0; j < XB; ++j) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[(wn * (TK / 2) + j * 32 + (lane & 31)) * LDW + kk]);
+            for (int j = 0; j < XD; ++j) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[(wna * (TK / WNA) + j * 32 + (lane & 31)) * LDW + kk]);
                 accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, accx[j], 0, 0, 0);
             }
         }
         __syncthreads();   // every wave is through with the x' tile: its buffer takes the dx rows
         u16 *const St = Xs;
 #pragma unroll
-        for (int j = 0; j < XB; ++j)
+        for (int j = 0; j < XD; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                St[(wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * LDS_ + wn * (TK / 2) + j * 32 + (lane & 31)] = f2bf(accx[j][i]);
+                St[(wma * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * LDS_ + wna * (TK / WNA) + j * 32 + (lane & 31)] = f2bf(accx[j][i]);
         __syncthreads();
         // store dx (= dz of the layer below) as 16-byte row segments and add its BatchNorm-backward sums: this thread owns
         // the same (row, chunk) positions it loaded y_below at -- the raw rows are requested again (L2: they were read a
@@ -1403,7 +1411,7 @@ __global__ __launch_bounds__(256, 2) void bwd_fused_kernel(Operand A_arg, Operan
             red[(rowk * 2 + 1) * TK + chk * 8 + e] = rs2[e];
         }
         __syncthreads();
-        for (int o = t; o < 2 * TK; o += 256) {
+        for (int o = t; o < 2 * TK; o += THREADS) {
             const int m = o / TK, c = o % TK;
             float a = 0.0f;
             for (int r = 0; r < RPK; ++r) a += red[(r * 2 + m) * TK + c];
@@ -1418,7 +1426,7 @@ __global__ __launch_bounds__(256, 2) void bwd_fused_kernel(Operand A_arg, Operan
             const int n = wn * (TK / 2) + b * 32 + (lane & 31);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int m = wm * (TC / 2) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int m = wm * (TC / WMB) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 if (m < C && n < K) part[(long)blockIdx.x * C * K + (long)m * K + n] = accw[a][b][i];
             }
         }
@@ -1856,8 +1864,8 @@ extern "C" int pcb_gemm_tn_bias_bf16(const void *dy, const void *x, long R, int 
 // below's BatchNorm-backward sums as `nparts` slabs red_sums [nparts][2][K].  dy from (dz | dout + argmax, y) with
 // scale / shift / p / q (pro 2 / 3 as pcb_gemm_nt_bf16); x' = act(x * xscale + xshift) with the layer below's raw rows x
 // (= red_y: the same tensor) and its mean / invstd.  wt = the layer's prepared transposed weight [K, C].
-// C, K multiples of 8, at most 128; 1 <= nparts <= PCB_MAX_SLABS (the grid).
-extern "C" int pcb_bwd_fused_supported(int C, int K) { return C > 0 && K > 0 && !(C & 7) && !(K & 7) && C <= 128 && K <= 128; }
+// C, K multiples of 8, C <= 256, K <= 128; 1 <= nparts <= PCB_MAX_SLABS (the grid).
+extern "C" int pcb_bwd_fused_supported(int C, int K) { return C > 0 && K > 0 && !(C & 7) && !(K & 7) && C <= 256 && K <= 128; }
 
 extern "C" int pcb_bwd_fused_bf16(int pro, const void *dz, const void *y, const float *scale, const float *shift, const float *p,
                                   const float *q, const float *dout, const unsigned char *argmax, int ns, int act,
@@ -1882,20 +1890,22 @@ extern "C" int pcb_bwd_fused_bf16(int pro, const void *dz, const void *y, const 
     hipEvent_t timed;
     pcb_timer_begin(st, &timed);
     const dim3 grid((unsigned)nparts);
-#define PCB_BF_LAUNCH(P, TC_, TK_)                                                                                              \
-    hipLaunchKernelGGL((bwd_fused_kernel<P, TC_, TK_>), grid, dim3(256), 0, st, A, X, (const u16 *)wt, R, C, K, (u16 *)dx, red, \
-                       red_sums, workspace)
+#define PCB_BF_LAUNCH(P, TC_, TK_, W_)                                                                                              \
+    hipLaunchKernelGGL((bwd_fused_kernel<P, TC_, TK_, W_>), grid, dim3(W_ * 64), 0, st, A, X, (const u16 *)wt, R, C, K, (u16 *)dx, \
+                       red, red_sums, workspace)
     const bool wc = C > 64, wk = K > 64;
     if (pro == PRO_DY) {
-        if (wc && wk) PCB_BF_LAUNCH(PRO_DY, 128, 128);
-        else if (wc) PCB_BF_LAUNCH(PRO_DY, 128, 64);
-        else if (wk) PCB_BF_LAUNCH(PRO_DY, 64, 128);
-        else PCB_BF_LAUNCH(PRO_DY, 64, 64);
+        if (C > 128) PCB_BF_LAUNCH(PRO_DY, 256, 128, 8);
+        else if (wc && wk) PCB_BF_LAUNCH(PRO_DY, 128, 128, 4);
+        else if (wc) PCB_BF_LAUNCH(PRO_DY, 128, 64, 4);
+        else if (wk) PCB_BF_LAUNCH(PRO_DY, 64, 128, 4);
+        else PCB_BF_LAUNCH(PRO_DY, 64, 64, 4);
     } else {
-        if (wc && wk) PCB_BF_LAUNCH(PRO_DY_POOL, 128, 128);
-        else if (wc) PCB_BF_LAUNCH(PRO_DY_POOL, 128, 64);
-        else if (wk) PCB_BF_LAUNCH(PRO_DY_POOL, 64, 128);
-        else PCB_BF_LAUNCH(PRO_DY_POOL, 64, 64);
+        if (C > 128) PCB_BF_LAUNCH(PRO_DY_POOL, 256, 128, 8);
+        else if (wc && wk) PCB_BF_LAUNCH(PRO_DY_POOL, 128, 128, 4);
+        else if (wc) PCB_BF_LAUNCH(PRO_DY_POOL, 128, 64, 4);
+        else if (wk) PCB_BF_LAUNCH(PRO_DY_POOL, 64, 128, 4);
+        else PCB_BF_LAUNCH(PRO_DY_POOL, 64, 64, 4);
     }
 #undef PCB_BF_LAUNCH
     // algorithmic bytes: the dy operand as its prologue reads it, the rows of the layer below once, dx written once

@@ -702,7 +702,7 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
                                                 ptr<float>(a.ext[X_DADD1]), (int)a.ext[X_SH2], ptr<float>(a.ext[X_DADD2]),
                                                 stream));
             }
-            // a narrow inner layer (C, K <= 128): input gradient, weight gradient and the sums of the layer below from ONE
+            // a narrow inner layer (C <= 256, K <= 128): input gradient, weight gradient and the sums of the layer below from ONE
             // pass over (dz, y) and the rows below (bwd_fused_kernel) instead of gemm_tn + gemm_nt_red
             static const bool fused_off = getenv("PCB_BWD_FUSED") && atoi(getenv("PCB_BWD_FUSED")) == 0;
             if (!fused_off && dtype == PCB_DTYPE_BF16 && l > 0 && a.dW && parts && !side && apro >= 2 && !a.ext &&
@@ -710,7 +710,9 @@ extern "C" int pcb_mlp_stack_backward(int dtype, int L, const long long *desc, c
                 const Layer &b = ly[l - 1];
                 long rps;
                 long grid = (R + 63) / 64;                                    // row tiles of the kernel
-                const long cap = 512 - 2L * busy > 64 ? 512 - 2L * busy : 64;  // two workgroups per CU it may use
+                // two workgroups per CU it may use (C <= 128), one of eight waves (C <= 256: 131 KB of LDS)
+                const long per_cu = a.C > 128 ? 1 : 2;
+                const long cap = per_cu * (256 - busy) > 64 ? per_cu * (256 - busy) : 64;
                 const long slabs = pcb_tn_splits(R, a.C, a.kp, &rps, 512);     // what the caller's workspace region holds
                 grid = grid < cap ? grid : cap;
                 grid = grid < slabs ? grid : slabs;

@@ -173,7 +173,8 @@ def test_a_captured_step_survives_other_models_and_their_operand_sets():
 
 
 @pytest.mark.parametrize("pro,R,C,K,ns", [(2, 4096, 128, 128, 1), (2, 1000, 64, 64, 1), (3, 2048, 128, 64, 16), (3, 999 * 8, 64, 128, 8),
-                                          (2, 64 * 600, 72, 40, 1), (3, 70 * 32, 128, 128, 32), (2, 50, 8, 8, 1)])
+                                          (2, 64 * 600, 72, 40, 1), (3, 70 * 32, 128, 128, 32), (2, 50, 8, 8, 1),
+                                          (3, 4096, 256, 128, 32), (2, 3000, 200, 96, 1)])
 def test_fused_layer_backward_equals_the_two_kernel_form(pro, R, C, K, ns):
     """pcb_bwd_fused_bf16 (one pass over (dz, y) and the rows below: dx, dW, the sums of the layer below) against
     pcb_gemm_nt_red_bf16 + pcb_gemm_tn_bf16, the pair it replaces for the narrow layers: dx bit-identical (the same
@@ -181,7 +182,7 @@ def test_fused_layer_backward_equals_the_two_kernel_form(pro, R, C, K, ns):
     from pointcloud_bridge_amd import _lib
     from pointcloud_bridge_amd.ops import _launch
     L = _lib.load()
-    assert L.pcb_bwd_fused_supported(C, K) == 1 and L.pcb_bwd_fused_supported(256, 64) == 0 and L.pcb_bwd_fused_supported(60, 64) == 0
+    assert L.pcb_bwd_fused_supported(C, K) == 1 and L.pcb_bwd_fused_supported(264, 64) == 0 and L.pcb_bwd_fused_supported(64, 136) == 0 and L.pcb_bwd_fused_supported(60, 64) == 0
     g = torch.Generator().manual_seed(R + C)
     dev = torch.device("cuda")
     y = torch.randn(R, C, generator=g).to(dev).to(torch.bfloat16)
