@@ -168,7 +168,7 @@ class Run:
         # inference through one captured hipGraph per batch (pn2_msg / pn2_ssg: the eager eval pass is bound by the
         # host -- ~160 launches, 2.4-2.8 ms of enqueueing against 2.6 ms of GPU time)
         self.infer_graph = mode == "infer" and graph and hasattr(model, "static_sampling") and model_name in ("pn2_msg", "pn2_ssg")
-        if self.use_graph and (model_name == "bridgeseg" or loss == "bridge"):
+        if self.use_graph and loss == "bridge":
             # The narrow encoder layers of BridgeSeg and BridgeStructureLoss still run ATen BatchNorm /
             # reductions.  ATen's two-stage reductions (staging buffer + semaphores) return garbage on every
             # replay of a captured hipGraph but the first on this stack (tools/graph_reduce_repro.py, a
@@ -576,7 +576,7 @@ def main():
     # and runs the timed region with the faster one (the same decision on every rank: maximum over ranks).
     exec_mode = "graph" if args.graph else args.exec
     probes = {}
-    can_graph = (args.mode == "train" and args.model in ("pn2_msg", "pn2_ssg", "dgcnn") and args.loss == "ce"
+    can_graph = (args.mode == "train" and args.model in ("pn2_msg", "pn2_ssg", "dgcnn", "bridgeseg") and args.loss == "ce"
                  and not args.dump and not args.no_prefetch)
     if exec_mode == "auto" and args.mode == "infer" and args.model in ("pn2_msg", "pn2_ssg") and not args.no_prefetch:
         exec_mode = "graph"     # the eval pass is host-bound when launched kernel by kernel (2.77 vs 2.61 ms captured)

@@ -479,6 +479,31 @@ int pcb_bwd_fused_bf16(int pro, const void *dz, const void *y, const float *scal
                        int xact, long R, int C, int K, void *dx, float *red_sums, int nparts, float *workspace, float *dW,
                        int out_cols, int out_perm, void *stream);
 
+/*
+ * BatchNorm (+ ReLU / LeakyReLU) on NARROW fp32 rows [R, C], any 1 <= C <= 64, and per-scene column sums: the colour /
+ * fusion stacks of the reference's BridgeSeg network (models/attention_modules.py:696-722, :759-764: BatchNorm1d over 3, 6
+ * or 16 channels on B*N rows; color_context's AdaptiveAvgPool1d).  Kernels only, no atomics: valid inside a captured step.
+ *   pcb_rows_bn_stats_f32           slabs [nparts][2][C] of (sum x, sum x^2), nparts = pcb_rows_bn_partials(R, C) exactly;
+ *                                   pcb_bn_finalize(slabs, nparts, R, ...) makes scale / shift / mean / invstd of them
+ *   pcb_rows_bn_act_f32             z = act(x*scale + shift)
+ *   pcb_rows_bn_act_bwd_reduce_f32  slabs [nparts][2][C] of (sum du, sum du*xhat) (add them with pcb_sum_slabs)
+ *   pcb_rows_bn_act_bwd_apply_f32   dx = scale*(du - s1/R - xhat*s2/R) with sums = (s1, s2), or scale*du (use_batch_stats 0)
+ *   pcb_scene_sum_f32               slabs [nparts][B][C] of the column sums of each scene's N rows of x [B*N, C],
+ *                                   nparts = pcb_scene_sum_partials(N) exactly (pcb_sum_slabs(slabs, nparts, B*C, out))
+ */
+int pcb_rows_bn_partials(long R, int C);
+int pcb_rows_bn_stats_f32(const float *x, long R, int C, float *slabs, int nparts, void *stream);
+int pcb_rows_bn_act_f32(const float *x, const float *scale, const float *shift, long R, int C, int act, float *z,
+                        void *stream);
+int pcb_rows_bn_act_bwd_reduce_f32(const float *dz, const float *x, const float *scale, const float *shift,
+                                   const float *mean, const float *invstd, long R, int C, int act, float *slabs,
+                                   int nparts, void *stream);
+int pcb_rows_bn_act_bwd_apply_f32(const float *dz, const float *x, const float *scale, const float *shift,
+                                  const float *mean, const float *invstd, const float *sums, long R, int C, int act,
+                                  int use_batch_stats, float *dx, void *stream);
+int pcb_scene_sum_partials(int N);
+int pcb_scene_sum_f32(const float *x, int B, int N, int C, float *slabs, int nparts, void *stream);
+
 /* Tell the library that another kernel occupies about `busy_cus` compute units beside the launches
  * that follow (e.g. the next batch's FPS on a side stream during the backward pass): the persistent
  * GEMMs without slabs, the weight-gradient splits and the slab-count recommendation then leave

@@ -47,6 +47,13 @@ SIGNATURES = {
     "pcb_bn_act_bwd_apply_bf16": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
     "pcb_bn_act_bwd_apply_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
     "pcb_sum_slabs": [_p, _i, _i, _p, _p],
+    "pcb_rows_bn_partials": [_l, _i],
+    "pcb_rows_bn_stats_f32": [_p, _l, _i, _p, _i, _p],
+    "pcb_rows_bn_act_f32": [_p, _p, _p, _l, _i, _i, _p, _p],
+    "pcb_rows_bn_act_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _i, _p],
+    "pcb_rows_bn_act_bwd_apply_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p],
+    "pcb_scene_sum_partials": [_i],
+    "pcb_scene_sum_f32": [_p, _i, _i, _i, _p, _i, _p],
     "pcb_bn_finalize": [_p, _i, _l, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p],
     "pcb_set_concurrency_hint": [_i],
     "pcb_gemm_nt_partials": [_i, _l, _i],

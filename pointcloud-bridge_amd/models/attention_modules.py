@@ -48,10 +48,21 @@ def _rows_conv(conv, x):
 
 
 def _rows_seq_f32(seq, x):
-    """An nn.Sequential of 1x1 Conv / BatchNorm / ReLU / Sigmoid on fp32 rows [R, C]."""
-    for m in seq:
+    """An nn.Sequential of 1x1 Conv / BatchNorm / ReLU / Sigmoid on fp32 rows [R, C].  BatchNorm (with the ReLU behind
+    it) runs on the narrow-row kernels (rowsf32.bn_act_rows: any channel count, kernels only -- a captured step may
+    contain it); SyncBatchNorm and a handful of rows stay with ATen."""
+    seq = list(seq)
+    i = 0
+    while i < len(seq):
+        m = seq[i]
+        i += 1
         if isinstance(m, (nn.Conv1d, nn.Conv2d)):
             x = _rows_conv(m, x)
+        elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)) and not isinstance(m, nn.SyncBatchNorm) \
+                and x.is_cuda and x.shape[0] >= 1024 and x.shape[1] <= rowsf32.MAX_CHANNELS:
+            relu = i < len(seq) and isinstance(seq[i], nn.ReLU)
+            x = rowsf32.bn_act_rows(m, x, rowsf32.ACT_RELU if relu else rowsf32.ACT_NONE)
+            i += int(relu)
         elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.SyncBatchNorm)):
             x = rowmlp._bn_rows_fp32(m, x)
         elif isinstance(m, nn.ReLU):
@@ -160,7 +171,12 @@ class BridgeStructureEncoding(nn.Module):
         hit = _geometry.pop(self._geometry_key(xyz), None)
         if hit is not None and hit[3]() is not xyz:
             hit = None
-        if hit is None:
+        from . import pointnet2_utils as pu
+        static = pu.static_sampling()
+        job = static.lookup_job(("geometry", id(self)), xyz) if static is not None else None
+        if job is not None:
+            per_point, rel = job         # a captured step: computed beside the previous step's backward pass (StaticSampling)
+        elif hit is None:
             per_point, rel = self.geometry(xyz)
         else:
             per_point, rel, ev, _ = hit
@@ -228,8 +244,8 @@ class ColorFeatureExtraction(nn.Module):
         """colors [B*N, 3] fp32 -> [B*N, out_channels]."""
         feat = _rows_seq_f32(self.color_mlp, colors_rows)                        # :724
         local = feat * _rows_seq_f32(self.color_attention, feat)                 # :746-747
-        ctx = _rows_seq_f32(list(self.color_context)[1:], feat.view(B, N, -1).mean(dim=1))  # :750
-        return (local.view(B, N, -1) * ctx.unsqueeze(1)).view(B * N, -1)         # :751
+        ctx = _rows_seq_f32(list(self.color_context)[1:], rowsf32.scene_mean(feat, B, N))    # :750
+        return rowsf32.scene_scale(local, ctx, B, N)                             # :751
 
     def forward(self, colors, xyz=None):
         B, _, N = colors.shape

@@ -266,6 +266,15 @@ class EnhancedPointNet2(_SamplingPrefetchMixin, nn.Module):
         self.bri_enc.prefetch(xyz)
         super().prefetch(xyz)
 
+    def static_sampling(self, xyz):
+        """The pipeline of a captured step: the trunk's (pyramid, ball queries, decoder k-NN) plus the neighbourhood
+        geometry of the three BridgeStructureEncoding modules -- bri_enc on the input cloud, geometric2 / geometric3 on
+        levels 2 and 3 -- which depend on coordinates only (models/attention_modules.py:584-603)."""
+        static = super().static_sampling(xyz)
+        for level, enc in ((0, self.bri_enc), (2, self.geometric2.br_pos), (3, self.geometric3.br_pos)):
+            static.jobs.append((("geometry", id(enc)), level, enc.geometry))
+        return static
+
     def forward(self, xyz, features=None):
         B, N, _ = xyz.shape
         pos = self.bri_enc.rows(xyz)                                              # :119

@@ -205,12 +205,15 @@ class StaticSampling:
     SetAbstraction / MultiScaleSetAbstraction / the propagation stages read the live buffers (see _sample,
     _ball_indices, _nearest, _interp_csr) while a pipeline is installed with set_static_sampling()."""
 
-    def __init__(self, xyz, npoints, balls=None, propagation=None):
+    def __init__(self, xyz, npoints, balls=None, propagation=None, jobs=None):
         B, N, _ = xyz.shape
         dev = xyz.device
         self.levels = []
         self.balls = balls
         self.propagation = list(propagation or ())
+        # further coordinate-only work of the model: (key, level, fn) -- fn(cloud of that level) -> tuple of tensors,
+        # computed with the pyramid, staged and committed like the rest, found by lookup_job(key, cloud)
+        self.jobs = list(jobs or ())
         self.extra = {}   # key -> (live tensors, staging tensors), allocated at the first compute()
         n_in = N
         # FPS start indices of all levels: ONE device buffer, filled by one asynchronous copy per draw() from a ring of
@@ -266,6 +269,8 @@ class StaticSampling:
                 self._stage(("ball", l), _ball_indices_now(radii, nsamples, cur, lv["new_xyz_s"]))
             cur = lv["new_xyz_s"]
             clouds.append(cur)
+        for key, level, fn in self.jobs:
+            self._stage(("job", key), tuple(fn(clouds[level])))
         for fine, coarse, k in self.propagation:
             nn_res = ops.three_nn(clouds[fine], clouds[coarse], k)
             self._stage(("nn", fine, coarse, int(k)), nn_res)
@@ -339,6 +344,14 @@ class StaticSampling:
         held = self.extra.get(("ball", l - 1))
         return None if held is None else held[0]
 
+    def lookup_job(self, key, xyz):
+        """The live results of job `key` if `xyz` is the live cloud of the job's level, else None."""
+        for k, level, _ in self.jobs:
+            if k == key and self._level_of(xyz) == level:
+                held = self.extra.get(("job", key))
+                return None if held is None else held[0]
+        return None
+
     def lookup_extra(self, kind, xyz1, xyz2, k):
         f, c = self._level_of(xyz1), self._level_of(xyz2)
         held = self.extra.get((kind, f, c, int(k))) if f is not None and c is not None else None
@@ -352,6 +365,10 @@ def set_static_sampling(pipeline):
     """Install (or remove, with None) a StaticSampling pipeline for subsequent forward passes."""
     global _static
     _static = pipeline
+
+
+def static_sampling():
+    return _static
 
 
 def _sample(xyz, npoint):

@@ -10,7 +10,7 @@ reduce pass + finalize + apply pass (the same BatchNorm-backward algebra as the 
 import torch
 
 from . import _lib
-from .ops import _launch, on_device
+from .ops import _launch, on_device, sum_slabs
 from .rowmlp import _bn_bookkeeping, _counter
 
 
@@ -71,8 +71,8 @@ class _NeighbourMLP(torch.autograd.Function):
             _launch("pcb_nbr_mlp_backward_apply", P * k * C * C, base.data_ptr(), rel.data_ptr(), P, k, C,
                     wr.data_ptr(), consts[0].data_ptr(), consts[1].data_ptr(), pq[0].data_ptr(), pq[1].data_ptr(),
                     w2.data_ptr(), g.data_ptr(), arg.data_ptr(), dbase.data_ptr(), dwrp.data_ptr())
-        dw2 = dw2p.sum(dim=0)
-        return (dbase, None, dwrp.sum(dim=0), pq[2].clone() if has_affine else None,
+        dw2 = sum_slabs(dw2p)
+        return (dbase, None, sum_slabs(dwrp), pq[2].clone() if has_affine else None,
                 pq[3].clone() if has_affine else None, dw2[:, :C].contiguous(),
                 dw2[:, C].contiguous() if has_b2 else None, None, None, None, None, None, None)
 

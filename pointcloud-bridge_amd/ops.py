@@ -392,6 +392,19 @@ def segment_sum(rows, col0, C, order, offsets, out, accumulate=False):
     return out
 
 
+def sum_slabs(slabs):
+    """slabs [n, ...] fp32 -> their sum over the first axis, added in slab order by one small kernel (fp64 accumulation).
+    torch.sum(dim=0) is the same number up to rounding, but ATen's reductions go multi-stage (staging buffer +
+    semaphore) at sizes it chooses, and those do not survive hipGraph replay on this stack (tools/graph_reduce_repro.py):
+    every partial-sum total of this package that may run inside a captured step goes through here."""
+    slabs = slabs.contiguous()
+    n = slabs.shape[0]
+    out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
+    with on_device(slabs.device):
+        _launch("pcb_sum_slabs", slabs.numel(), slabs.data_ptr(), n, out.numel(), out.data_ptr())
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # differentiable ops
 # --------------------------------------------------------------------------------------------

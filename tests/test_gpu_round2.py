@@ -470,8 +470,12 @@ def test_confusion_matrices_on_device_equal_the_per_point_loop():
 
 
 @pytest.mark.gpu
-def test_captured_pn2_msg_step_equals_the_eager_step():
-    """The captured hipGraph step of bench.py (static sampling pipeline: FPS pyramid, ball queries, decoder k-NN and
+@pytest.mark.parametrize("model_name", ["pn2_msg", "bridgeseg"])
+def test_captured_pn2_msg_step_equals_the_eager_step(model_name):
+    """(bridgeseg, round 3: the reference's whole BridgeSeg network -- its colour / fusion stacks run BatchNorm on the
+    narrow-row kernels and every partial-sum total goes through pcb_sum_slabs, so the step holds no ATen reduction any
+    more and replays; the neighbourhood geometry of its three structure encoders rides in the static pipeline.)
+    The captured hipGraph step of bench.py (static sampling pipeline: FPS pyramid, ball queries, decoder k-NN and
     inverted indices of the NEXT batch computed on a side stream into a staging set, committed at the top of the
     next replay) against the same step launched kernel by kernel: same batches in the same order, same FPS start
     indices -> the same gradients up to the run-to-run spread of the step (fp32 atomics in the gathered set
@@ -483,7 +487,7 @@ def test_captured_pn2_msg_step_equals_the_eager_step():
     from pointcloud_bridge_amd.models import pointnet2_utils as pu
     args = argparse.Namespace(no_dropout=True, no_prefetch=False, dump=False)
     dev = torch.device("cuda", 0)
-    run = bench.Run(args, "pn2_msg", "bf16", 4, 4096, 0, 1, dev, graph=True)
+    run = bench.Run(args, model_name, "bf16", 4, 4096, 0, 1, dev, graph=True)
     try:
         run.opt.step = lambda *a, **k: None      # parameters stay put: gradients of different steps are comparable
 
