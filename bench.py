@@ -168,13 +168,6 @@ class Run:
         # inference through one captured hipGraph per batch (pn2_msg / pn2_ssg: the eager eval pass is bound by the
         # host -- ~160 launches, 2.4-2.8 ms of enqueueing against 2.6 ms of GPU time)
         self.infer_graph = mode == "infer" and graph and hasattr(model, "static_sampling") and model_name in ("pn2_msg", "pn2_ssg")
-        if self.use_graph and loss == "bridge":
-            # The narrow encoder layers of BridgeSeg and BridgeStructureLoss still run ATen BatchNorm /
-            # reductions.  ATen's two-stage reductions (staging buffer + semaphores) return garbage on every
-            # replay of a captured hipGraph but the first on this stack (tools/graph_reduce_repro.py, a
-            # torch-only reproducer) -- a captured step must not contain one.
-            raise SystemExit("--graph: the BridgeSeg encoders / BridgeStructureLoss still contain ATen reductions, which "
-                             "do not survive hipGraph replay on this PyTorch-ROCm build (tools/graph_reduce_repro.py)")
         params = [p for p in model.parameters() if p.requires_grad]
         self.params = params
         # train_MulSca_PN2.py:125: Adam(lr=1e-3, weight_decay=1e-4) -- as one fused update over a flat
@@ -189,6 +182,9 @@ class Run:
         for i in range(self.RESIDENT_BATCHES):
             if strong:
                 x, c, lab = synthetic_batch(B * world, N, 1000 + 17 * i, "cpu", family)
+                if getattr(args, "dup_halves", False):
+                    h = B * world // 2
+                    x, c, lab = (torch.cat([t[:h], t[:h]]) for t in (x, c, lab))
                 sl = slice(rank * B, (rank + 1) * B)
                 self.batches.append(tuple(t[sl].contiguous().to(device) for t in (x, c, lab)))
             else:
@@ -545,6 +541,9 @@ def main():
                     help="row type of the fused MLP engine: bf16 activations (BASELINE config 2) or fp32 rows (parity mode)")
     ap.add_argument("--dump", default=None, help="rank 0 writes step losses and the final parameters to this .pt file")
     ap.add_argument("--no-dropout", action="store_true", help="Dropout layers with p = 0 (sharded-vs-single equivalence runs)")
+    ap.add_argument("--dup-halves", action="store_true",
+                    help="--scaling strong: the second half of the global batch repeats the first (equivalence runs of a criterion "
+                         "with batch-level statistics -- BridgeStructureLoss: every rank's shard then has the global batch's)")
     args = ap.parse_args()
 
     from pointcloud_bridge_amd import parallel
@@ -576,7 +575,7 @@ def main():
     # and runs the timed region with the faster one (the same decision on every rank: maximum over ranks).
     exec_mode = "graph" if args.graph else args.exec
     probes = {}
-    can_graph = (args.mode == "train" and args.model in ("pn2_msg", "pn2_ssg", "dgcnn", "bridgeseg") and args.loss == "ce"
+    can_graph = (args.mode == "train" and args.model in ("pn2_msg", "pn2_ssg", "dgcnn", "bridgeseg") and args.loss in ("ce", "bridge")
                  and not args.dump and not args.no_prefetch)
     if exec_mode == "auto" and args.mode == "infer" and args.model in ("pn2_msg", "pn2_ssg") and not args.no_prefetch:
         exec_mode = "graph"     # the eval pass is host-bound when launched kernel by kernel (2.77 vs 2.61 ms captured)

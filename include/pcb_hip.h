@@ -878,6 +878,27 @@ int pcb_cross_entropy_bwd(const float *logits, long ld, const int64_t *labels, l
                           const float *loss_count, const float *grad_out, float *dlogits, void *stream);
 
 /*
+ * The criterion of the reference's BridgeSeg trainer, BridgeStructureLoss (models/model.py:169-260;
+ * train_MulSca_BriStruNet_CB.py:151-156, :178), as kernels -- its torch form runs ~40 reductions over [B,N] masks per step.
+ *   pcb_bridge_loss_weights   the 5 class weights of the step: per scene, from the PREDICTED labels (arg-max of the logits
+ *                             rows [B*N, >=5], `ld` floats apart) and the z coordinates of points [B,N,3], the mean relative
+ *                             height of each predicted component class (:189-196) and the order violations between them
+ *                             (:218-251), averaged over the scenes, times 1/sqrt(label frequency) * {1,2,1,1,2}
+ *                             (:253-256).  stats: scratch [B][22] floats; weights [5] out; base_weights [5] in.  B <= 1024.
+ *   pcb_cross_entropy_w_fwd / _bwd   F.cross_entropy(logits, labels, weight=w, label_smoothing=eps) (:258-260): loss =
+ *                             sum_i [(1-eps) w[y_i] (-logp_i[y_i]) + eps/C sum_c w[c] (-logp_i[c])] / sum_i w[y_i];
+ *                             loss_wsum [2] = (loss, sum of the label weights); partials as pcb_cross_entropy_fwd.
+ */
+int pcb_bridge_loss_weights(const float *logits, long ld, const int64_t *labels, const float *points, int B, int N,
+                            float alpha, float rel_margin, const float *base_weights, float *stats, float *weights,
+                            void *stream);
+int pcb_cross_entropy_w_fwd(const float *logits, long ld, const int64_t *labels, long R, int C, long ignore_index,
+                            const float *weight, float smoothing, float *partials, float *loss_wsum, void *stream);
+int pcb_cross_entropy_w_bwd(const float *logits, long ld, const int64_t *labels, long R, int C, long ignore_index,
+                            const float *weight, float smoothing, const float *loss_wsum, const float *grad_out,
+                            float *dlogits, void *stream);
+
+/*
  * Instruments of bench.py (off unless armed; the only other process-wide state besides the hint):
  *  - HIP-event timing, on the stream they are launched on, of two kernel categories:
  *      0  the gemm_nt family (pcb_gemm_nt_* / pcb_gemm_nt_red_* / _bias / _f32out, also when issued

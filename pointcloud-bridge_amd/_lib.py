@@ -148,6 +148,9 @@ SIGNATURES = {
     "pcb_cross_entropy_partials": [_l],
     "pcb_cross_entropy_fwd": [_p, _l, _p, _l, _i, _l, _p, _p, _p],
     "pcb_cross_entropy_bwd": [_p, _l, _p, _l, _i, _l, _p, _p, _p, _p],
+    "pcb_bridge_loss_weights": [_p, _l, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p],
+    "pcb_cross_entropy_w_fwd": [_p, _l, _p, _l, _i, _l, _p, _f, _p, _p, _p],
+    "pcb_cross_entropy_w_bwd": [_p, _l, _p, _l, _i, _l, _p, _f, _p, _p, _p, _p],
 }
 
 _lib = None

@@ -43,6 +43,16 @@ class BridgeStructureLoss(nn.Module):
 
     def forward(self, outputs, labels, points):
         """outputs [B,5,N] logits, labels [B,N] int64, points [B,N,3] -> scalar loss."""
+        rows = _as_rows(outputs, False) if outputs.is_cuda else None
+        if (rows is not None and rows.shape[1] == 5 and labels.is_cuda and labels.device == outputs.device
+                and labels.dtype == torch.int64 and points.is_cuda and points.device == outputs.device
+                and labels.numel() == rows.shape[0] and labels.shape[0] <= 1024):
+            # GPU: two kernels for the class weights, the weighted + smoothed cross entropy on the logits rows in place
+            # (csrc/loss.hip) -- no ATen reduction: the criterion may sit inside a captured step
+            B, N = labels.shape
+            w = _bridge_weights(rows, labels.reshape(-1).contiguous(), points.float().contiguous(), B, N, float(self.alpha),
+                                float(self.rel_margin), self.base_weights_buffer.to(outputs.device, torch.float32))
+            return _CrossEntropyRowsW.apply(rows, labels.reshape(-1).contiguous(), w, 0.2, -100)
         logits = outputs.transpose(1, 2)
         B = labels.shape[0]
         with torch.no_grad():
@@ -101,6 +111,49 @@ class _CrossEntropyRows(torch.autograd.Function):
             _launch("pcb_cross_entropy_bwd", R * C, rows.data_ptr(), rows.stride(0), labels.data_ptr(), R, C,
                     ctx.ignore_index, out.data_ptr(), g.data_ptr(), d.data_ptr())
         return d, None, None
+
+
+def _bridge_weights(rows, labels, points, B, N, alpha, rel_margin, base):
+    from .ops import _launch, on_device
+    dev = rows.device
+    stats = torch.empty(B, 22, dtype=torch.float32, device=dev)
+    w = torch.empty(5, dtype=torch.float32, device=dev)
+    with on_device(dev):
+        _launch("pcb_bridge_loss_weights", B * N * 5, rows.data_ptr(), rows.stride(0), labels.data_ptr(), points.data_ptr(), B, N,
+                alpha, rel_margin, base.contiguous().data_ptr(), stats.data_ptr(), w.data_ptr())
+    return w
+
+
+class _CrossEntropyRowsW(torch.autograd.Function):
+    """F.cross_entropy(rows, labels, weight=w, label_smoothing=eps) over logits rows [R, C] fp32 (csrc/loss.hip); the
+    class weights are data (no gradient), as in the reference (computed under no_grad, models/model.py:203)."""
+
+    @staticmethod
+    def forward(ctx, rows, labels, w, eps, ignore_index):
+        from .ops import _launch, on_device
+        R, C = rows.shape
+        dev = rows.device
+        partials = torch.empty(2 * _lib.load().pcb_cross_entropy_partials(R), dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        with on_device(dev):
+            _launch("pcb_cross_entropy_w_fwd", R * C, rows.data_ptr(), rows.stride(0), labels.data_ptr(), R, C, int(ignore_index),
+                    w.data_ptr(), float(eps), partials.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(rows, labels, w, out)
+        ctx.cfg = (float(eps), int(ignore_index))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import _launch, on_device
+        rows, labels, w, out = ctx.saved_tensors
+        eps, ignore_index = ctx.cfg
+        R, C = rows.shape
+        d = torch.empty(R, C, dtype=torch.float32, device=rows.device)
+        g = g.to(torch.float32).contiguous()
+        with on_device(rows.device):
+            _launch("pcb_cross_entropy_w_bwd", R * C, rows.data_ptr(), rows.stride(0), labels.data_ptr(), R, C, ignore_index,
+                    w.data_ptr(), eps, out.data_ptr(), g.data_ptr(), d.data_ptr())
+        return d, None, None, None, None
 
 
 def _as_rows(logits, channels_last):
