@@ -312,6 +312,9 @@ class Run:
             static.compute(xyz_next)
         side = torch.cuda.Stream()
         loss_buf = torch.zeros((), device=self.device)
+        want = getattr(self.args, "graph_segments", 0) or (2 if self.coll else 1)
+        if want == 2 and hasattr(model, "_cut"):
+            return self._capture_two_segments(model, opt, xyz, colors, labels, xyz_next, batch, static, side, loss_buf)
 
         def fwd_bwd():
             self.rowmlp.prepare_step(model)      # operands of every stack from the weights the last Adam step left
@@ -378,6 +381,123 @@ class Run:
             return loss_buf
 
         self.graph_step, self.eager_step, self.static = graph_step, eager_step, static
+
+    def _capture_two_segments(self, model, opt, xyz, colors, labels, xyz_next, batch, static, side, loss_buf):
+        """The captured step as TWO hipGraphs split at the seam between encoder and decoder, so that the gradient exchange
+        overlaps the backward pass in captured mode too (one flat all-reduce behind the whole replay left
+        the links idle during the backward pass and the chip idle during the exchange):
+            graph A   forward, loss, backward of head + decoder down to the seam; their gradients packed into the tail
+                      of the flat gradient buffer
+            (host)    asynchronous all-reduce of that tail -- RCCL's stream; it waits for graph A only
+            graph B   backward of the encoder from the seam's gradients; packed into the head of the flat buffer
+            (host)    all-reduce of the head, wait for both, average, fused Adam
+        The seam: models.containers._SamplingPrefetchMixin.decoder_cut detaches what the encoder hands to the decoder;
+        autograd runs from the loss to the detached tensors (A) and from the encoder's outputs with those gradients (B).
+        Both graphs share one memory pool (B reads what A's forward pass saved)."""
+        from pointcloud_bridge_amd import ops
+        names = [n for n, _ in model.named_children()]
+        k = names.index(model.decoder_first)
+        enc_ids = {id(p) for _, child in list(model.named_children())[:k] for p in child.parameters()}
+        E = [p for p in self.params if id(p) in enc_ids]
+        D = [p for p in self.params if id(p) not in enc_ids]
+        if [id(p) for p in E + D] != [id(p) for p in self.params]:
+            raise SystemExit("--graph-segments 2: the encoder's parameters are not a prefix of the parameter list")
+        nE = sum(p.numel() for p in E)
+        flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=self.device)
+        self.bucket.flat = flat
+        seam = {}
+
+        def cut(*ts):
+            seam["enc"] = ts
+            seam["dec"] = tuple(t.detach().requires_grad_(t.requires_grad) for t in ts)
+            return seam["dec"]
+
+        model.decoder_cut = cut
+
+        def pack(grads, params, out):
+            torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, params)], out=out)
+
+        def seg_a():
+            self.rowmlp.prepare_step(model)
+            if static is not None:
+                static.commit()
+            loss = self.loss_of(model(xyz, colors), batch)
+            if static is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    static.compute(xyz_next)
+                ops.set_background_work(torch.cuda.Event(), 2 * xyz.shape[0])
+            dec = [t for t in seam["dec"] if t.requires_grad]
+            grads = torch.autograd.grad(loss, dec + D, allow_unused=True)
+            seam["bgrads"] = [g if g is not None else torch.zeros_like(t) for g, t in zip(grads[:len(dec)], dec)]
+            pack(grads[len(dec):], D, flat[nE:])
+            if static is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            loss_buf.copy_(loss.detach())
+
+        def seg_b():
+            enc = [t for t in seam["enc"] if t.requires_grad]
+            pack(torch.autograd.grad(enc, E, grad_outputs=seam["bgrads"], allow_unused=True), E, flat[:nE])
+
+        def exchange_tail():
+            return dist.all_reduce(flat[nE:], op=dist.ReduceOp.SUM, async_op=True) if self.coll else None
+
+        def exchange_head(work):
+            if self.coll:
+                dist.all_reduce(flat[:nE], op=dist.ReduceOp.SUM)
+                work.wait()
+                flat.div_(self.world)
+
+        self.segment_log = []   # (tests) the order in which segments and exchanges were issued in the last step
+
+        def run_step(a, b):
+            self.segment_log = ["A"]
+            a()
+            work = exchange_tail()
+            self.segment_log += ["allreduce(decoder)", "B"]
+            b()
+            exchange_head(work)
+            self.segment_log += ["allreduce(encoder)"]
+            opt.step(flat)
+
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(3):                   # eager warm-up on the capture stream
+                if static is not None:
+                    static.draw()
+                run_step(seg_a, seg_b)
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        if static is not None:
+            static.draw()
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            seg_a()
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+            seg_b()
+
+        def load_batches():
+            cur, nxt = self._batch(), self._batch(1)
+            xyz.copy_(cur[0]); colors.copy_(cur[1]); labels.copy_(cur[2])
+            xyz_next.copy_(nxt[0])
+            self.i += 1
+
+        def graph_step():
+            load_batches()
+            if static is not None:
+                static.draw()
+            run_step(ga.replay, gb.replay)
+            return loss_buf
+
+        def eager_step():
+            load_batches()
+            if static is not None:
+                static.draw()
+            run_step(seg_a, seg_b)
+            return loss_buf
+
+        self.graph_step, self.eager_step, self.static, self.segments = graph_step, eager_step, static, 2
 
     # -- the timed loop ---------------------------------------------------------------------------
     def fence(self):
@@ -502,6 +622,8 @@ class Run:
         pu.set_scene_shard(0, 1)
         if hasattr(self.bucket, "close"):
             self.bucket.close()
+        if getattr(self.model, "decoder_cut", None) is not None:
+            self.model.decoder_cut = None
 
 
 def main():
@@ -541,6 +663,9 @@ def main():
                     help="row type of the fused MLP engine: bf16 activations (BASELINE config 2) or fp32 rows (parity mode)")
     ap.add_argument("--dump", default=None, help="rank 0 writes step losses and the final parameters to this .pt file")
     ap.add_argument("--no-dropout", action="store_true", help="Dropout layers with p = 0 (sharded-vs-single equivalence runs)")
+    ap.add_argument("--graph-segments", type=int, default=0, choices=[0, 1, 2],
+                    help="captured step as ONE hipGraph (1) or as TWO split at the encoder/decoder seam, the decoder's gradient "
+                         "bucket all-reduced while the encoder's backward segment replays (2); 0 = 2 with more than one rank, else 1")
     ap.add_argument("--dup-halves", action="store_true",
                     help="--scaling strong: the second half of the global batch repeats the first (equivalence runs of a criterion "
                          "with batch-level statistics -- BridgeStructureLoss: every rank's shard then has the global batch's)")
@@ -667,7 +792,9 @@ def main():
         whole = res["lib_bytes_per_step"] / step_s / 1e9
         workload = (f"{args.model} "
                     + (("fwd+" + ("CE" if args.loss == "ce" else "BridgeStructureLoss") + "+bwd+"
-                        + ("flat gradient packing" if world == 1 else
+                        + ("two graph segments, the decoder's gradient bucket all-reduced beside the encoder's backward segment"
+                           if (exec_mode == "graph" and getattr(run, "segments", 1) == 2) else
+                           "flat gradient packing" if world == 1 else
                            ("one flat grad-allreduce" if exec_mode == "graph" else "overlapped bucketed grad-allreduce"))
                         + "+Adam" + (", captured hipGraph step" if exec_mode == "graph" else ""))
                        if args.mode == "train" else

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void nbr_bwd_reduce_kernel(
     __shared__ float red[kWaves * 2 * CM];
     __shared__ int map[2 * CM];
     __shared__ float s_mean[CM], s_invstd[CM];
-    __shared__ float s_dw2[CM][CM + 1];
+    __shared__ float s_dw2[kWaves][CM][CM + 1];   // one slot per wave: plain adds by its lane 0, summed in wave order (no atomics: reproducible)
     load_weights<CM>(w, C, wr, scale, shift, w2, nullptr);
     for (int e = threadIdx.x; e < 2 * CM; e += kThreads) {
         const int which = e / CM, c = e - which * CM;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void nbr_bwd_reduce_kernel(
             s_invstd[c] = c < C ? invstd[c] : 0.0f;
         }
     }
-    for (int e = threadIdx.x; e < CM * (CM + 1); e += kThreads) (&s_dw2[0][0])[e] = 0.0f;
+    for (int e = threadIdx.x; e < kWaves * CM * (CM + 1); e += kThreads) (&s_dw2[0][0][0])[e] = 0.0f;
     __syncthreads();
     float acc[2 * CM];
 #pragma unroll
@@ -254,17 +254,19 @@ __global__ __launch_bounds__(kThreads) void nbr_bwd_reduce_kernel(
                     if (d < C) {
                         const float zd = fmaxf(fmaf(w.scale[d], y1[d], w.shift[d]), 0.0f);
                         const float s = wave_sum(go[c] * zd);
-                        if (lane == 0) atomicAdd(&s_dw2[c][d], s);
+                        if (lane == 0) s_dw2[threadIdx.x >> 6][c][d] += s;
                     }
                 const float sg = wave_sum(go[c]);
-                if (lane == 0) atomicAdd(&s_dw2[c][CM], sg);
+                if (lane == 0) s_dw2[threadIdx.x >> 6][c][CM] += sg;
             }
     }
     block_sums<2 * CM>(acc, red, sums + (long)blockIdx.x * 2 * C, 2 * C, map);
     __syncthreads();
     for (int e = threadIdx.x; e < C * (C + 1); e += kThreads) {
         const int c = e / (C + 1), d = e - c * (C + 1);
-        dw2[(long)blockIdx.x * C * (C + 1) + e] = s_dw2[c][d < C ? d : CM];
+        float a = 0.0f;
+        for (int wv = 0; wv < kWaves; ++wv) a += s_dw2[wv][c][d < C ? d : CM];
+        dw2[(long)blockIdx.x * C * (C + 1) + e] = a;
     }
 }
 

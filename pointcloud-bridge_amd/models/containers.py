@@ -19,6 +19,16 @@ from .pointnet2_utils import (EnhancedFeaturePropagation, FeaturePropagation, Mu
 
 class _SamplingPrefetchMixin:
     _next_xyz = None
+    # The seam between encoder and decoder: a callable (tensors...) -> tensors applied to everything the encoder hands to
+    # the decoder, or None.  A step captured as TWO hipGraphs (bench.py, parallel: the decoder's gradient bucket travels
+    # while the encoder's backward pass still runs) installs one that detaches the tensors and records both sides, so that
+    # autograd can be run down to the seam and, separately, from the seam to the inputs.
+    decoder_cut = None
+    # (first top-level child module of the decoder: the parameters in front of it form the encoder's gradient bucket)
+    decoder_first = "fp3"
+
+    def _cut(self, *tensors):
+        return tensors if self.decoder_cut is None else tuple(self.decoder_cut(*tensors))
 
     def prefetch(self, xyz):
         """Start the FPS pyramid of the NEXT batch's coordinates on a side stream (see
@@ -100,6 +110,7 @@ class PointNet2(_SamplingPrefetchMixin, nn.Module):
         l2_xyz, l2 = self.sa2(l1_xyz, l1)
         l3_xyz, l3 = self.sa3(l2_xyz, l2)
         self._start_next()
+        l1, l2, l3 = self._cut(l1, l2, l3)
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, points if self.rgb_skip else None, l1)
@@ -214,6 +225,7 @@ class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):
         l2_xyz, l2 = self.sa2(l1_xyz, l1)
         l3_xyz, l3 = self.sa3(l2_xyz, l2)
         self._start_next()
+        l1, l2, l3 = self._cut(l1, l2, l3)
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
         l0 = self.fp1(xyz, l1_xyz, feats, l1)
@@ -286,9 +298,10 @@ class EnhancedPointNet2(_SamplingPrefetchMixin, nn.Module):
         l3_xyz, l3 = self.sa3(l2_xyz, l2)
         l3 = self.geometric3(l3, l3_xyz)                                          # :136
         self._start_next()
+        l1, l2, l3, fused_dec = self._cut(l1, l2, l3, fused_in)
         l2 = self.fp3(l2_xyz, l3_xyz, l2, l3)
         l1 = self.fp2(l1_xyz, l2_xyz, l1, l2)
-        l0 = self.fp1(xyz, l1_xyz, fused_in, l1)
+        l0 = self.fp1(xyz, l1_xyz, fused_dec, l1)
         # fusion's upsample + concatenate [B,N,384] and final_fusion's first conv as one layer over the three levels
         outs, reps, B, N = self.fusion.levels([l2, l1, l0])
         ff = self.final_fusion

@@ -271,3 +271,72 @@ def test_cfg4_two_ranks_bridgeseg_bridge_loss_syncbn(tmp_path):
     # the averaged gradient.  A broken exchange (a missing all-reduce, unsynchronised statistics, a shard taking the wrong
     # scenes) shows as O(1).
     assert l2 < 0.1 and q99 < 2e-2
+
+
+@pytest.mark.parametrize("model_name", ["pn2_msg", "bridgeseg"])
+def test_two_segment_captured_step_equals_the_one_graph_step(model_name):
+    """the captured step split into two hipGraphs at the encoder/decoder seam (bench.Run._capture_two_segments:
+    the decoder's gradient bucket is all-reduced between the two replays, beside the encoder's backward segment) must
+    compute what the one-graph step computes.  Run in the reproducible mode, where 'the same' means the same bits:
+    losses and flat gradients of an eager step and two replays, after identical warm-up / Adam histories.  (With float
+    atomics the two runs' warm-up steps already differ in the last bits, Adam's sign-like first updates amplify that
+    into different weights, and nothing downstream is comparable.)  Also: the issue order of segments and exchanges."""
+    import argparse
+    import bench
+    from pointcloud_bridge_amd import ops
+    from pointcloud_bridge_amd.models import pointnet2_utils as pu
+    dev = torch.device("cuda", 0)
+
+    def flat_of(segments):
+        args = argparse.Namespace(no_dropout=True, no_prefetch=False, dump=False, graph_segments=segments)
+        torch.manual_seed(3)                         # the captures' own FPS draws
+        run = bench.Run(args, model_name, "bf16", 4, 4096, 0, 1, dev, graph=True)
+        try:
+            assert getattr(run, "segments", 1) == segments
+            out = []
+            for step in (run.eager_step, run.graph_step, run.graph_step):
+                torch.manual_seed(11)
+                step()
+                loss = step()
+                torch.cuda.synchronize()
+                out.append((float(loss), run.bucket.flat.clone(), run.opt.flat.clone()))
+            if segments == 2:
+                assert run.segment_log == ["A", "allreduce(decoder)", "B", "allreduce(encoder)"]
+            return out
+        finally:
+            run.close()
+            pu.set_static_sampling(None)
+
+    old = ops.set_deterministic(True)
+    try:
+        one, two = flat_of(1), flat_of(2)
+    finally:
+        ops.set_deterministic(old)
+    for (la, ga, pa), (lb, gb, pb) in zip(one, two):
+        assert la == lb
+        assert torch.equal(ga, gb)                   # the averaged gradient the optimiser consumed
+        assert torch.equal(pa, pb)                   # ... and the parameters after it (six Adam steps so far)
+
+
+def test_two_segment_step_on_a_one_rank_rccl_group(tmp_path):
+    """The same on the real backend: PCB_DIST_SINGLE=1 makes bench.py join a one-rank `nccl` (= RCCL) group, so the two
+    asynchronous all-reduces of the segmented step are real collectives issued between the replays.  Losses against the
+    plain single-process run (one graph, no group)."""
+    import json
+    from tests.helpers import free_port
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "4", "--warmup", "2", "--npoints", "4096", "--batch", "4", "--no-cpu-baseline", "--no-extras",
+              "--no-dropout", "--exec", "graph"]
+    plain = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + common, env=env, capture_output=True, text=True,
+                           timeout=600)
+    assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-4000:]
+    rccl = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(repo, "bench.py")]
+                          + common + ["--graph-segments", "2"], env=dict(env, PCB_DIST_SINGLE="1"), capture_output=True,
+                          text=True, timeout=600)
+    assert rccl.returncode == 0, rccl.stdout[-2000:] + rccl.stderr[-4000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(rccl.stdout.strip().splitlines()[-1])
+    assert "two graph segments" in b["config"]["workload"] and b["config"]["graph"]
+    assert abs(a["config"]["loss"] - b["config"]["loss"]) < 3e-2 * abs(a["config"]["loss"])
