@@ -504,6 +504,14 @@ int pcb_rows_bn_act_bwd_apply_f32(const float *dz, const float *x, const float *
 int pcb_scene_sum_partials(int N);
 int pcb_scene_sum_f32(const float *x, int B, int N, int C, float *slabs, int nparts, void *stream);
 
+/* nn.Dropout on rows (the Dropout(0.5) in front of the segmentation heads' last conv, models/model.py:97, models/model.py:52):
+ * out = x * keep / (1 - p), keep from a stateless 64-bit mix of (*seed, 16-byte vector index) -- 8 bits per element, p rounded
+ * to a multiple of 1/256.  The backward pass is the SAME call on the gradient with the same seed (nothing is stored).  seed:
+ * an int64 in device memory (a captured step replays the launch; whatever refreshes *seed inside the graph refreshes the
+ * mask).  n elements, a multiple of 8 (bf16) / 4 (fp32); x may equal out. */
+int pcb_dropout_rows_bf16(const void *x, long n, const long long *seed, float p, void *out, void *stream);
+int pcb_dropout_rows_f32(const void *x, long n, const long long *seed, float p, void *out, void *stream);
+
 /* Tell the library that another kernel occupies about `busy_cus` compute units beside the launches
  * that follow (e.g. the next batch's FPS on a side stream during the backward pass): the persistent
  * GEMMs without slabs, the weight-gradient splits and the slab-count recommendation then leave

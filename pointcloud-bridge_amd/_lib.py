@@ -102,6 +102,8 @@ SIGNATURES = {
     "pcb_segment_sum_f32": [_p, _l, _i, _i, _p, _p, _l, _p, _l, _i, _p],
     "pcb_segment_sum_bf16": [_p, _l, _i, _i, _p, _p, _l, _p, _l, _i, _p],
     "pcb_scatter_dy_csr_bf16": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _l, _p, _p],
+    "pcb_dropout_rows_bf16": [_p, _l, _p, _f, _p, _p],
+    "pcb_dropout_rows_f32": [_p, _l, _p, _f, _p, _p],
     "pcb_gate_bf16": [_p, _p, _p, _l, _p],
     "pcb_gate_f32": [_p, _p, _p, _l, _p],
     "pcb_gate_bwd_bf16": [_p, _p, _p, _p, _p, _l, _p],

@@ -584,6 +584,36 @@ __global__ __launch_bounds__(kThreads) void gate_bwd_kernel(const uint4 *__restr
     }
 }
 
+// Dropout on rows (nn.Dropout(0.5) in front of the segmentation heads' last conv, models/model.py:97, :52): out = x * keep /
+// (1 - p) with a STATELESS mask: keep bits come from a 64-bit mix of (seed, vector index), 8 bits per element (p in steps of
+// 1/256), so the backward pass applies the very same launch to the gradient with the same seed and nothing is stored.
+// ATen: a fused kernel + a bool mask tensor forward (39 us for [262144,128] bf16), masked_scale backward (70 us).
+// The seed is read from device memory: a captured step replays the launch and draws fresh masks from a seed tensor that an
+// RNG op inside the graph refreshes.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void dropout_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ out, long nvec,
+                                                            const long long *__restrict__ seed, unsigned threshold,
+                                                            float scale)
+{
+    constexpr int E = RowVec<T>::E;
+    const unsigned long long s = mix64((unsigned long long)seed[0]);
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < nvec; e += (long)gridDim.x * kThreads) {
+        const unsigned long long h = mix64(s ^ ((unsigned long long)e * 0xd1342543de82ef95ull));
+        float f[E];
+        RowVec<T>::unpack(x[e], f);
+#pragma unroll
+        for (int i = 0; i < E; ++i) f[i] = ((unsigned)(h >> (8 * i)) & 0xffu) >= threshold ? f[i] * scale : 0.0f;
+        out[e] = RowVec<T>::pack(f);
+    }
+}
+
 // Raw fp32 input columns (coordinates, colours: [R, k] with k = 3) as a zero-padded GEMM operand [R, kp] of
 // the row type: cast + pad in one pass (ATen: a cast, a zero fill and a strided copy).
 template <typename T>
@@ -798,6 +828,21 @@ int gate(const void *x, const void *a, void *out, long n, void *stream)
 }
 
 template <typename T>
+int dropout_rows(const void *x, long n, const long long *seed, float p, void *out, void *stream)
+{
+    constexpr int E = RowVec<T>::E;
+    if (!x || !out || !seed || n <= 0 || (n % E) || !(p >= 0.0f && p < 1.0f)) return PCB_ERR_INVALID_ARG;
+    const unsigned threshold = (unsigned)(p * 256.0f + 0.5f);   // P(drop) = threshold / 256
+    if (threshold >= 256) return PCB_ERR_INVALID_ARG;
+    const float scale = 256.0f / (float)(256 - threshold);
+    const long nvec = n / E;
+    hipLaunchKernelGGL(dropout_kernel<T>, dim3(grid_for(nvec, kThreads, 8192)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4 *)x, (uint4 *)out, nvec, seed, threshold, scale);
+    pcb_account(2.0 * sizeof(T) * n);
+    return pcb_check_launch();
+}
+
+template <typename T>
 int gate_bwd(const void *g, const void *x, const void *a, void *dx, void *da, long n, void *stream)
 {
     constexpr int E = RowVec<T>::E;
@@ -812,6 +857,15 @@ int gate_bwd(const void *g, const void *x, const void *a, void *dx, void *da, lo
 }  // namespace
 
 extern "C" {
+
+int pcb_dropout_rows_bf16(const void *x, long n, const long long *seed, float p, void *out, void *stream)
+{
+    return dropout_rows<pcb_bf16>(x, n, seed, p, out, stream);
+}
+int pcb_dropout_rows_f32(const void *x, long n, const long long *seed, float p, void *out, void *stream)
+{
+    return dropout_rows<float>(x, n, seed, p, out, stream);
+}
 
 int pcb_colstats_bf16(const void *y, long rows, int C, float *sums, void *stream) { return colstats<pcb_bf16>(y, rows, C, sums, 0, stream); }
 int pcb_colstats_f32(const void *y, long rows, int C, float *sums, void *stream) { return colstats<float>(y, rows, C, sums, 0, stream); }

@@ -116,7 +116,7 @@ class PointNet2(_SamplingPrefetchMixin, nn.Module):
         l0 = self.fp1(xyz, l1_xyz, points if self.rgb_skip else None, l1)
         B, _, N = l0.shape
         feat = rowmlp.conv_bn_act(self.conv1, self.bn1, _channels_last(l0).view(B * N, -1))
-        logits = rowmlp.conv_rows(self.conv2, self.drop1(feat), torch.float32)
+        logits = rowmlp.conv_rows(self.conv2, rowmlp.dropout_rows(self.drop1, feat), torch.float32)
         return logits.view(B, N, -1).transpose(1, 2)
 
 
@@ -234,7 +234,7 @@ class PointNet2MSG(_SamplingPrefetchMixin, nn.Module):
         ff = self.final_fusion
         x = rowmlp.conv_bn_act_levels(ff[0], ff[1], outs, reps,
                                       concat=lambda: self.fusion.concat(outs, reps, B, N).view(B * N, -1))
-        logits = rowmlp.conv_rows(ff[4], ff[3](x), torch.float32)
+        logits = rowmlp.conv_rows(ff[4], rowmlp.dropout_rows(ff[3], x), torch.float32)
         return logits.view(B, N, -1).transpose(1, 2)
 
 
@@ -307,5 +307,5 @@ class EnhancedPointNet2(_SamplingPrefetchMixin, nn.Module):
         ff = self.final_fusion
         x = rowmlp.conv_bn_act_levels(ff[0], ff[1], outs, reps,
                                       concat=lambda: self.fusion.concat(outs, reps, B, N).view(B * N, -1))
-        logits = rowmlp.conv_rows(ff[4], ff[3](x), torch.float32)
+        logits = rowmlp.conv_rows(ff[4], rowmlp.dropout_rows(ff[3], x), torch.float32)
         return logits.view(B, N, -1).transpose(1, 2)

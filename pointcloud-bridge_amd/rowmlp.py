@@ -1387,6 +1387,44 @@ class _Gate(torch.autograd.Function):
         return dx, da, None
 
 
+class _DropoutRows(torch.autograd.Function):
+    """nn.Dropout on rows with a stateless mask (pcb_dropout_rows_*): forward and backward are the same launch with the
+    same seed; the seed is one int64 drawn on the device by torch's generator (under a captured graph that draw is the
+    graph-safe one: every replay gets a fresh seed)."""
+
+    @staticmethod
+    def forward(ctx, x, p, m):
+        seed = torch.randint(0, 1 << 62, (1,), dtype=torch.int64, device=x.device)
+        out = torch.empty_like(x)
+        with on_device(x.device):
+            _launch("pcb_dropout_rows_" + m.sfx, x.numel(), x.data_ptr(), x.numel(), seed.data_ptr(), float(p), out.data_ptr())
+        ctx.save_for_backward(seed)
+        ctx.cfg = (float(p), m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (seed,) = ctx.saved_tensors
+        p, m = ctx.cfg
+        g = g.to(m.dtype).contiguous()
+        dx = torch.empty_like(g)
+        with on_device(g.device):
+            _launch("pcb_dropout_rows_" + m.sfx, g.numel(), g.data_ptr(), g.numel(), seed.data_ptr(), p, dx.data_ptr())
+        return dx, None, None
+
+
+def dropout_rows(drop, x):
+    """drop(x) for an nn.Dropout module and rows x of the mode's type: the library's stateless-mask kernel in training
+    mode (one pass forward, one backward, no mask tensor), identity in eval mode; other dtypes / layouts go to the module."""
+    m = mode()
+    if not drop.training or drop.p == 0.0:
+        return x
+    if (x.is_cuda and x.dtype == m.dtype and x.is_contiguous() and x.numel() % m.q == 0 and 0.0 < drop.p < 1.0
+            and os.environ.get("PCB_DROPOUT_KERNEL", "1") != "0"):    # (A/B knob: tools/ab_env.sh)
+        return _DropoutRows.apply(x, drop.p, m)
+    return drop(x)
+
+
 def gate_rows(x, a):
     """x * sigmoid(a) (the channel-attention gate, reference pointnet2_utils.py:279-280)."""
     m = mode()

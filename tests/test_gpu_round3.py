@@ -340,3 +340,30 @@ def test_two_segment_step_on_a_one_rank_rccl_group(tmp_path):
     b = json.loads(rccl.stdout.strip().splitlines()[-1])
     assert "two graph segments" in b["config"]["workload"] and b["config"]["graph"]
     assert abs(a["config"]["loss"] - b["config"]["loss"]) < 3e-2 * abs(a["config"]["loss"])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_dropout_rows_stateless_mask(precision):
+    """rowmlp.dropout_rows (nn.Dropout(0.5) of the heads, models/model.py:97): kept elements scaled by 1/(1-p), the
+    keep rate, a fresh mask per call, the SAME mask in the backward pass, identity in eval mode."""
+    from pointcloud_bridge_amd import rowmlp
+    with rowmlp.precision(precision):
+        m = rowmlp.mode()
+        drop = torch.nn.Dropout(0.5).train()
+        torch.manual_seed(1)
+        x = (torch.rand(4096, 128, device="cuda") + 0.5).to(m.dtype).requires_grad_(True)
+        y = rowmlp.dropout_rows(drop, x)
+        kept = y != 0
+        assert abs(float(kept.float().mean()) - 0.5) < 0.01
+        assert torch.equal(y[kept].float(), (x.detach()[kept].float() * 2).to(m.dtype).float())
+        # columns / rows are not correlated with the mask in any obvious way
+        assert float(kept.float().mean(0).std()) < 0.02 and float(kept.float().mean(1).std()) < 0.08
+        g = torch.ones_like(y)
+        y.backward(g)
+        assert torch.equal(x.grad != 0, kept) and torch.equal(x.grad[kept].float(), torch.full_like(x.grad[kept], 2.0).float())
+        y2 = rowmlp.dropout_rows(drop, x)
+        assert not torch.equal(y2 != 0, kept)
+        drop.p = 0.25
+        assert abs(float((rowmlp.dropout_rows(drop, x) != 0).float().mean()) - 0.75) < 0.01
+        drop.eval()
+        assert rowmlp.dropout_rows(drop, x) is x
