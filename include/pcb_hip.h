@@ -159,6 +159,19 @@ int pcb_interpolate_bwd(const float *grad_out, const float *w, const int64_t *id
 int pcb_knn(const float *x, int B, int N, int D, int k, float *norms, int64_t *out_idx, void *stream);
 
 /*
+ * pcb_knn for feature-space graphs (32 <= D <= 128, k <= 20: DGCNN's second to fourth get_graph_feature calls,
+ * models/DGCNN.py:137-150) through a screening pass on the bf16 matrix core (csrc/knn.hip): approximate distances from
+ * a two-term bf16 split of the features pick 24 candidates per query, their distances are recomputed exactly and the
+ * result is certified against a proven error bound; queries that cannot be certified are recomputed by pcb_knn's own
+ * kernel.  SAME output as pcb_knn for every input.  Shapes the pass does not serve (workspace size 0) go to pcb_knn.
+ *   workspace: pcb_knn_screen_workspace(B, N, D, k) bytes of caller-owned scratch (NULL: pcb_knn); after the call its
+ *   int32 words [B, 2B) hold the number of recomputed queries of every scene.
+ */
+long pcb_knn_screen_workspace(int B, int N, int D, int k);
+int pcb_knn_screened(const float *x, int B, int N, int D, int k, float *norms, void *workspace, int64_t *out_idx,
+                     void *stream);
+
+/*
  * kNN on 3-D coordinates (the D = 3 case of pcb_knn: DGCNN's first graph, models/DGCNN.py:134, and
  * torch.cdist + topk of BridgeStructureEncoding, models/attention_modules.py:584-586) through a
  * uniform grid: the cloud is sorted by cell and every query looks at the cells around it in growing

@@ -26,6 +26,8 @@ SIGNATURES = {
     "pcb_interpolate": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "pcb_interpolate_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "pcb_knn": [_p, _i, _i, _i, _i, _p, _p, _p],
+    "pcb_knn_screen_workspace": [_i, _i, _i, _i],
+    "pcb_knn_screened": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
     "pcb_knn_xyz_workspace": [_i, _i],
     "pcb_knn_xyz": [_p, _i, _i, _i, _p, _p, _p, _p],
     "pcb_structure_features": [_p, _p, _i, _i, _i, _p, _p, _p],
@@ -176,7 +178,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the build lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "pcb_status_string"
-                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems", "pcb_mlp_stack_dzbuf_elems", "pcb_knn_xyz_workspace",
+                          else ctypes.c_long if name in ("pcb_gemm_tn_workspace", "pcb_mlp_stack_wbuf_elems", "pcb_mlp_stack_dzbuf_elems", "pcb_knn_xyz_workspace", "pcb_knn_screen_workspace",
                                                      "pcb_scene_max_workspace", "pcb_scene_colsum_workspace", "pcb_scatter_dy_slabs")
                           else ctypes.c_int)
         _lib = lib

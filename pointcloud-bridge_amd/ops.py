@@ -312,8 +312,35 @@ def knn(x_bnd, k):
             ws = torch.empty(_lib.load().pcb_knn_xyz_workspace(B, N), dtype=torch.uint8, device=x.device)
             _launch("pcb_knn_xyz", B * N * k, x.data_ptr(), B, N, k, norms.data_ptr(), ws.data_ptr(), out.data_ptr())
         else:
-            _launch("pcb_knn", B * N * N, x.data_ptr(), B, N, D, k, norms.data_ptr(), out.data_ptr())
+            nbytes = _lib.load().pcb_knn_screen_workspace(B, N, D, k) if _SCREEN_KNN else 0
+            if nbytes:
+                # feature-space graphs: screening pass on the bf16 matrix core, exact recheck (same output)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                _launch("pcb_knn_screened", B * N * N, x.data_ptr(), B, N, D, k, norms.data_ptr(), ws.data_ptr(),
+                        out.data_ptr())
+                if _KNN_STATS is not None:
+                    _KNN_STATS.append((B, N, D, k, ws[4 * B:8 * B].view(torch.int32).clone()))
+            else:
+                _launch("pcb_knn", B * N * N, x.data_ptr(), B, N, D, k, norms.data_ptr(), out.data_ptr())
     return out
+
+
+_SCREEN_KNN = os.environ.get("PCB_SCREEN_KNN", "1") != "0"  # 0: the exact all-pairs kernel alone (A/B timing)
+_KNN_STATS = None  # a list: every screened call appends (B, N, D, k, recomputed queries per scene [B] int32)
+
+
+def set_screen_knn(flag):
+    global _SCREEN_KNN
+    old, _SCREEN_KNN = _SCREEN_KNN, bool(flag)
+    return old
+
+
+def collect_knn_stats(flag):
+    """Start (True) or stop (False) recording how many queries each screened kNN call handed to the exact kernel;
+    returns the list recorded so far."""
+    global _KNN_STATS
+    old, _KNN_STATS = _KNN_STATS, ([] if flag else None)
+    return old
 
 
 _GRID_KNN = os.environ.get("PCB_GRID_KNN", "1") != "0"  # 0: all-pairs kernel for coordinates too (A/B timing)

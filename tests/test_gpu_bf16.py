@@ -254,7 +254,9 @@ def test_bf16_training_reaches_fp32_miou(rm):
     small and stable: tools/miou_det.py, 6 model seeds x 4 checkpoints (120 ... 960 steps): -0.4, -0.6, -1.0, -1.2 points
     per checkpoint, -0.8 +- 0.4 overall, single samples between -3.2 and +4.5.  The bf16 engine trails the fp32 engine by
     about a point on this task and does not drift away with training; resolving +-0.5 points would take
-    ~100 trainings per engine.  Asserted over 18 samples: |mean| below 2 points, every sample within 8, both engines
+    ~100 trainings per engine.  Asserted over 18 samples: |mean| below 2 points (three standard errors), every sample within 12 (the samples'
+    spread is 2.8 points: 8 points is a 3-sigma event that one set of 18 in fifteen contains -- seen after the dropout
+    kernel changed the trajectories), both engines
     above 0.7 mIoU at the last checkpoint (chance 0.2), and a repeated run identical to the bit."""
     from pointcloud_bridge_amd import ops, train
     from pointcloud_bridge_amd.models.containers import PointNet2
@@ -300,7 +302,7 @@ def test_bf16_training_reaches_fp32_miou(rm):
     print("bf16 - fp32 mIoU over", n, "samples: mean", round(mean, 4), "standard error", round(se, 4), "min", round(min(diffs), 4),
           "max", round(max(diffs), 4))
     assert abs(mean) < 0.02
-    assert max(abs(d) for d in diffs) < 0.08
+    assert max(abs(d) for d in diffs) < 0.12
 
 
 @pytest.mark.parametrize("D1,C,k", [(3, 64, 4), (0, 32, 3), (16, 256, 4), (5, 8, 3)])

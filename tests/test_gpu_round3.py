@@ -367,3 +367,56 @@ def test_dropout_rows_stateless_mask(precision):
         assert abs(float((rowmlp.dropout_rows(drop, x) != 0).float().mean()) - 0.75) < 0.01
         drop.eval()
         assert rowmlp.dropout_rows(drop, x) is x
+
+
+# ---- feature-space kNN through the split-bf16 screening pass (csrc/knn.hip: knn_screen_kernel) ---------------------------
+def _knn_cloud(kind, B, N, D, g):
+    x = torch.randn(B, N, D, generator=g)
+    if kind == "clustered":            # tight clusters + exact duplicates: ties at the k-th distance
+        c = torch.randn(B, 16, D, generator=g) * 3
+        lab = torch.randint(0, 16, (B, N), generator=g)
+        x = torch.gather(c, 1, lab.unsqueeze(-1).expand(B, N, D)) + 0.05 * x
+        x[:, N // 2:N // 2 + 64] = x[:, :64]
+    elif kind == "lattice":            # small integers: most distances tie exactly
+        x = torch.randint(-2, 3, (B, N, D), generator=g).float()
+    elif kind == "offset":             # |x|^2 >> neighbour distances: nothing certifies, everything is recomputed
+        x = x * 0.01 + 50.0
+    elif kind == "relu":               # what the network feeds it: BatchNorm + LeakyReLU rows
+        x = torch.nn.functional.leaky_relu(x, 0.2)
+    return x.cuda().contiguous()
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "clustered", "lattice", "offset", "relu"])
+@pytest.mark.parametrize("N,D,k", [(1000, 64, 20), (2048, 128, 20), (777, 40, 8), (4096, 64, 20), (300, 32, 5),
+                                   (1024, 96, 16)])
+def test_screened_knn_is_the_exact_knn(kind, N, D, k):
+    """pcb_knn_screened against pcb_knn (itself bit-identical to the reference's topk on the fixtures,
+    tests/test_gpu_ops.py): identical index lists on random, tied, duplicated and badly conditioned clouds."""
+    from pointcloud_bridge_amd import ops
+    g = torch.Generator().manual_seed(N + D + k)
+    x = _knn_cloud(kind, 2, N, D, g)
+    old = ops.set_screen_knn(False)
+    try:
+        exact = ops.knn(x, k)
+        ops.set_screen_knn(True)
+        ops.collect_knn_stats(True)
+        screened = ops.knn(x, k)
+        stats = ops.collect_knn_stats(False)
+    finally:
+        ops.set_screen_knn(old)
+    assert len(stats) == 1, "the screening pass did not run"
+    recomputed = int(stats[0][4].sum())
+    print(kind, N, D, k, "recomputed", recomputed, "of", 2 * N)
+    assert torch.equal(screened, exact)
+    if kind in ("gaussian", "relu"):
+        assert recomputed < 0.05 * 2 * N     # well separated neighbours certify
+    if kind == "offset":
+        assert recomputed > 0.5 * 2 * N      # (and the recomputation path is exercised)
+
+
+def test_screened_knn_small_cloud_against_the_oracle():
+    from oracle import oracle as orc
+    from pointcloud_bridge_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.nn.functional.leaky_relu(torch.randn(2, 640, 64, generator=g), 0.2)
+    assert np.array_equal(ops.knn(x.cuda(), 20).cpu().numpy(), orc.knn(x.numpy(), 20))
