@@ -861,7 +861,13 @@ def extras(args, device):
         # the single-scale network the reference publishes its own numbers on (models/pointnet2.py), captured step
         ("pn2_ssg_graph_B16_N16384_bf16", dict(model_name="pn2_ssg", precision="bf16", B=16, N=16384, graph=True)),
         ("dgcnn_k20_B8_N8192_bf16", dict(model_name="dgcnn", precision="bf16", B=8, N=8192)),
+        ("dgcnn_k20_graph_B8_N8192_bf16", dict(model_name="dgcnn", precision="bf16", B=8, N=8192, graph=True)),
         ("bridgeseg_B16_N16384_bf16", dict(model_name="bridgeseg", precision="bf16", B=16, N=16384)),
+        # cfg4's network through the captured step (the eager step is bound by the host: ~770 launches), with the
+        # cross-entropy of the other rows and with the criterion cfg4 trains with (train_MulSca_BriStruNet_CB.py:151-156)
+        ("bridgeseg_graph_B16_N16384_bf16", dict(model_name="bridgeseg", precision="bf16", B=16, N=16384, graph=True)),
+        ("bridgeseg_bridge_loss_graph_B16_N16384_bf16", dict(model_name="bridgeseg", precision="bf16", B=16, N=16384, graph=True,
+                                                             loss="bridge")),
         ("pn2_msg_infer_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, mode="infer")),
         ("pn2_msg_infer_graph_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, mode="infer", graph=True)),
         # cfg5 as the reference runs it (inference_ptv3.py:48-51, :101-105) and on tiles of 16384 points

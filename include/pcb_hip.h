@@ -881,6 +881,10 @@ int pcb_pad_rows_f32(const float *x, long ld, long R, int k, int kp, void *out, 
  * `blocks` = their total.  (The captured training step hands the next step's sampling results from its staging to its
  * live buffers with it: StaticSampling.commit.) */
 int pcb_copy_table(const long long *table, int n, long blocks, void *stream);
+/* The same with the copies given as HOST arrays of n addresses / byte counts (passed to the kernel by value, 32 per
+ * launch): for source buffers whose addresses are only known when the call is made -- e.g. results allocated inside a
+ * captured step (StaticSampling.compute hands ball-query / three_nn / CSR results to its staging set with it). */
+int pcb_copy_list(const long long *dst, const long long *src, const long long *bytes, int n, void *stream);
 
 /*
  * Per-point cross entropy of the segmentation trainers (`criterion = nn.CrossEntropyLoss()` on [B,C,N]

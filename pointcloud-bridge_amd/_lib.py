@@ -147,6 +147,7 @@ SIGNATURES = {
     "pcb_bn_finalize_centred": [_p, _i, _l, _l, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "pcb_dy_repeat_sums_bf16": [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p, _p],
     "pcb_copy_table": [_p, _i, _l, _p],
+    "pcb_copy_list": [_p, _p, _p, _i, _p],
     "pcb_pad_rows_bf16": [_p, _l, _l, _i, _i, _p, _p],
     "pcb_pad_rows_f32": [_p, _l, _l, _i, _i, _p, _p],
     "pcb_cross_entropy_partials": [_l],

@@ -493,6 +493,56 @@ extern "C" int pcb_copy_table(const long long *table, int n, long blocks, void *
     return pcb_check_launch();
 }
 
+// The same with the rows passed BY VALUE in the kernel arguments (host arrays, up to 32 copies per launch): capturable
+// where the addresses only exist at capture time -- results a captured step allocates and copies to fixed buffers
+// (StaticSampling.compute: ball query / three_nn / CSR results into the staging set).
+struct CopyList {
+    long long row[32][4];
+};
+static __global__ __launch_bounds__(256) void copy_list_kernel(const CopyList list, int n)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (list.row[mid][3] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    char *const dst = reinterpret_cast<char *>(static_cast<uintptr_t>(list.row[lo][0]));
+    const char *const src = reinterpret_cast<const char *>(static_cast<uintptr_t>(list.row[lo][1]));
+    const long bytes = (long)list.row[lo][2];
+    const long base = ((long)blockIdx.x - (long)list.row[lo][3]) * 16384;
+    const long end = base + 16384 < bytes ? base + 16384 : bytes;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        for (long o = base + 16L * threadIdx.x; o + 16 <= end; o += 16 * 256)
+            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
+        for (long o = base + ((end - base) & ~15L) + 4L * threadIdx.x; o + 4 <= end; o += 4 * 256)
+            *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
+    } else {
+        for (long o = base + 4L * threadIdx.x; o + 4 <= end; o += 4 * 256)
+            *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
+    }
+}
+extern "C" int pcb_copy_list(const long long *dst, const long long *src, const long long *bytes, int n, void *stream)
+{
+    if (!dst || !src || !bytes || n < 1) return PCB_ERR_INVALID_ARG;
+    for (int first = 0; first < n; first += 32) {
+        CopyList list;
+        const int m = n - first < 32 ? n - first : 32;
+        long long blocks = 0;
+        for (int i = 0; i < m; ++i) {
+            const long long b = bytes[first + i];
+            if (b <= 0 || (b & 3) || ((dst[first + i] | src[first + i]) & 3)) return PCB_ERR_INVALID_ARG;
+            list.row[i][0] = dst[first + i];
+            list.row[i][1] = src[first + i];
+            list.row[i][2] = b;
+            list.row[i][3] = blocks;
+            blocks += (b + 16383) / 16384;
+        }
+        if (blocks > 0x7fffffffLL) return PCB_ERR_INVALID_ARG;
+        hipLaunchKernelGGL(copy_list_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, list, m);
+    }
+    return pcb_check_launch();
+}
+
 int pcb_copy_async(void *dst, const void *src, size_t bytes, hipStream_t st)
 {
     if (!dst || !src || (bytes & 3)) return PCB_ERR_INVALID_ARG;

@@ -215,6 +215,7 @@ class StaticSampling:
         # computed with the pyramid, staged and committed like the rest, found by lookup_job(key, cloud)
         self.jobs = list(jobs or ())
         self.extra = {}   # key -> (live tensors, staging tensors), allocated at the first compute()
+        self._pending = []  # (staging, result) pairs of the compute() under way
         n_in = N
         # FPS start indices of all levels: ONE device buffer, filled by one asynchronous copy per draw() from a ring of
         # pinned host buffers.  The host runs ahead of the GPU (a replay is enqueued in ~4 ms, executes in ~7): a single
@@ -254,8 +255,27 @@ class StaticSampling:
         held = self.extra.get(key)
         if held is None:  # first call: outside the capture (the warm-up steps)
             held = self.extra[key] = (tuple(torch.empty_like(r) for r in res), tuple(torch.empty_like(r) for r in res))
-        for h, r in zip(held[1], res):
-            h.copy_(r)
+        # (the copies of one compute() go out together: _flush_stage, one launch instead of two dozen copy nodes)
+        self._pending.extend((h, r) for h, r in zip(held[1], res))
+
+    def _flush_stage(self):
+        pend, self._pending = self._pending, []
+        if not pend:
+            return
+        ok = all(h.is_contiguous() and r.is_contiguous() and h.dtype == r.dtype and h.shape == r.shape
+                 and (h.numel() * h.element_size()) % 4 == 0 and h.numel() > 0 for h, r in pend)
+        if not ok:
+            for h, r in pend:
+                h.copy_(r)
+            return
+        import ctypes
+        n = len(pend)
+        arr = ctypes.c_longlong * n
+        dst = arr(*[h.data_ptr() for h, _ in pend])
+        src = arr(*[r.data_ptr() for _, r in pend])
+        nbytes = arr(*[h.numel() * h.element_size() for h, _ in pend])
+        with ops.on_device(pend[0][0].device):
+            ops._launch("pcb_copy_list", n, ctypes.addressof(dst), ctypes.addressof(src), ctypes.addressof(nbytes), n)
 
     def compute(self, xyz):
         """Enqueue everything for `xyz` (the NEXT step's coordinates) on the current stream, into the staging set."""
@@ -276,6 +296,7 @@ class StaticSampling:
             self._stage(("nn", fine, coarse, int(k)), nn_res)
             if torch.is_grad_enabled():
                 self._stage(("csr", fine, coarse, int(k)), rowmlp.build_interp_csr(nn_res[1], clouds[coarse].shape[1]))
+        self._flush_stage()
 
     def compute_beside(self, xyz, calls=1 << 30):
         """compute(xyz) on this pipeline's own side stream, forked from the current stream (pipelined inference

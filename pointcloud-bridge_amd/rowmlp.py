@@ -1125,7 +1125,7 @@ class _LinearBias(torch.autograd.Function):
     gradient with the split-row MFMA kernel (fp32, no atomics), bias gradient as a column sum."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_gap, m, res=None):
+    def forward(ctx, x, weight, bias, out_gap, m, res=None, out_dtype=None):
         """out_gap = D > 0: the output keeps the interpolate_concat column layout (first D outputs
         in place, the rest from column pad(D); untouched columns are exactly zero) and is returned
         with all its padded columns; out_gap = 0: plain [R, n] output.
@@ -1164,7 +1164,10 @@ class _LinearBias(torch.autograd.Function):
         ctx.save_for_backward(x, wt)
         ctx.cfg = (weight.shape, n, k, bias is not None, int(out_gap), npad, m)
         ctx.has_res = res is not None
-        return y if out_gap else y[:, :n]
+        out = y if out_gap else y[:, :n]
+        # (out_dtype inside the Function: the backward pass then gets the loss's fp32 rows and casts + pads them in one
+        # launch, instead of autograd's cast node followed by a pad)
+        return out if out_dtype is None or out.dtype == out_dtype else out.to(out_dtype)
 
     @staticmethod
     def backward(ctx, g):
@@ -1172,8 +1175,14 @@ class _LinearBias(torch.autograd.Function):
         wshape, n, k, has_bias, out_gap, npad, m = ctx.cfg
         R, kp = x.shape
         dev = x.device
-        gy = g.to(m.dtype)
-        gy = gy.contiguous() if gy.shape[1] == npad else F.pad(gy, (0, npad - gy.shape[1]))
+        if g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1 and (g.shape[1] != npad or not g.is_contiguous()):
+            # fp32 gradient rows of the real width (the loss's): cast + pad in one pass
+            gy = torch.empty(R, npad, dtype=m.dtype, device=dev)
+            with on_device(dev):
+                _launch("pcb_pad_rows_" + m.sfx, R * npad, g.data_ptr(), g.stride(0), R, g.shape[1], npad, gy.data_ptr())
+        else:
+            gy = g.to(m.dtype)
+            gy = gy.contiguous() if gy.shape[1] == npad else F.pad(gy, (0, npad - gy.shape[1]))
         dx = None
         dw = torch.empty(npad, k, dtype=torch.float32, device=dev)
         lib = _lib.load()
@@ -1204,9 +1213,9 @@ class _LinearBias(torch.autograd.Function):
                     db = sums[0]
         gres = g if ctx.has_res else None   # d(out)/d(res) = identity
         if not out_gap:
-            return dx, dw[:n].reshape(wshape), (db[:n].clone() if has_bias else None), None, None, gres
+            return dx, dw[:n].reshape(wshape), ((db if n == npad else db[:n].clone()) if has_bias else None), None, None, gres, None
         rows = _gap_row_index(n, out_gap, m.q, dev)
-        return dx, dw[rows].reshape(wshape), (db[rows] if has_bias else None), None, None, gres
+        return dx, dw[rows].reshape(wshape), (db[rows] if has_bias else None), None, None, gres, None
 
 
 def conv_rows(conv, x, out_dtype=None, out_gap=0, add=None):
@@ -1217,11 +1226,10 @@ def conv_rows(conv, x, out_dtype=None, out_gap=0, add=None):
     n = conv.out_channels
     if (add is not None and m.sfx == "bf16" and not out_gap and n % m.q == 0 and add.dtype == m.dtype
             and add.shape == (xr.shape[0], n) and add.is_contiguous()):
-        y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m, add)
-    else:
-        y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m)
-        if add is not None:
-            y = y + add
+        return _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m, add, out_dtype)
+    if add is None:
+        return _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m, None, out_dtype)
+    y = _LinearBias.apply(xr, conv.weight, conv.bias, out_gap, m) + add
     return y if out_dtype is None else y.to(out_dtype)
 
 
