@@ -769,7 +769,7 @@ def main():
                 and args.precision == "fp32" and world == 1):
             vs_baseline = res["points_per_s"] / 35557.0
         traffic = None  # HBM bytes per launch from the committed PMC passes of this same workload
-        for pmc_name in ("r02_pmc_gemm_nt_bf16.json", "r01_pmc_gemm_nt_bf16.json"):
+        for pmc_name in ("r03_pmc_gemm_nt_bf16.json", "r02_pmc_gemm_nt_bf16.json", "r01_pmc_gemm_nt_bf16.json"):
             pmc = os.path.join(REPO, "profiles", pmc_name)
             if (args.model == "pn2_msg" and args.precision == "bf16" and B == 16 and N == 16384 and args.data == "ball"
                     and args.mode == "train" and os.path.exists(pmc)):

@@ -11,8 +11,8 @@ def load(d, counter):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if r["Counter_Name"] == counter and ("gemm_nt_kernel" in n or "gemm_nt8_kernel" in n or "gemm_nt_ares_kernel" in n):
-            key = re.search(r"gemm_nt(?:_ares|8)?_kernel<[^>]*>", n).group(0)
+        if r["Counter_Name"] == counter and ("gemm_nt_kernel" in n or "gemm_nt8_kernel" in n or "gemm_nt_ares_kernel" in n or "bwd_fused_kernel" in n):
+            key = re.search(r"(?:gemm_nt(?:_ares|8)?|bwd_fused)_kernel<[^>]*>", n).group(0)
             per[key].append(float(r["Counter_Value"]))
     return per
 
@@ -25,7 +25,7 @@ f_kb = sum(sum(v) for v in fetch.values()) / nf
 w_kb = sum(sum(v) for v in write.values()) / nw
 out = {
     "command": sys.argv[4],
-    "kernel": "gemm_nt_kernel<*> + gemm_nt8_kernel<*> + gemm_nt_ares_kernel<*> (C entry points pcb_gemm_nt_bf16 / pcb_gemm_nt_red_bf16), all dispatches",
+    "kernel": "gemm_nt_kernel<*> + gemm_nt8_kernel<*> + gemm_nt_ares_kernel<*> + bwd_fused_kernel<*> (C entry points pcb_gemm_nt_bf16 / pcb_gemm_nt_red_bf16 / pcb_bwd_fused_bf16: the family bench.py times), all dispatches",
     "dispatches": nf,
     "FETCH_SIZE_KB_per_launch_raw": f_kb,
     "WRITE_SIZE_KB_per_launch": w_kb,
