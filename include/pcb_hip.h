@@ -650,6 +650,14 @@ int pcb_interpolate_bf16(const void *feat, const float *d2, const int64_t *idx, 
                          int k, void *out, int ld, int col0, float *out_w, void *stream);
 int pcb_interpolate_rows_f32(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C,
                              int k, void *out, int ld, int col0, float *out_w, void *stream);
+/* The same with FeaturePropagation's whole torch.cat([points1, interpolated], dim=-1) (:201 / :272) in one launch:
+ * out[row][0 .. d1) = skip[row][0 .. d1) (skip rows skip_ld elements apart, the row type), out[row][d1 .. col0) = 0. */
+int pcb_interpolate_skip_bf16(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C, int k,
+                              void *out, int ld, int col0, float *out_w, const void *skip, int skip_ld, int d1,
+                              void *stream);
+int pcb_interpolate_rows_skip_f32(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C, int k,
+                                  void *out, int ld, int col0, float *out_w, const void *skip, int skip_ld, int d1,
+                                  void *stream);
 
 /*
  * Backward of the interpolation without atomics: an inverted index of the (n,q) pairs by target

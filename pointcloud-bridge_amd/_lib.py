@@ -78,6 +78,8 @@ SIGNATURES = {
     "pcb_group_rows_bf16_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "pcb_group_rows_f32_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "pcb_interpolate_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
+    "pcb_interpolate_skip_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p],
+    "pcb_interpolate_rows_skip_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p],
     "pcb_interpolate_rows_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "pcb_interp_csr_count": [_p, _i, _i, _i, _i, _p, _p],
     "pcb_interp_csr_fill": [_p, _i, _i, _i, _i, _p, _p, _p, _p],

@@ -216,13 +216,28 @@ __global__ __launch_bounds__(256) void interpolate_rows_kernel(const T *__restri
                                                                 const int64_t *__restrict__ idx, int N, int S,
                                                                 int C, T *__restrict__ out, int ld,
                                                                 int col0, float *__restrict__ out_w,
-                                                                long nchunk)
+                                                                long nchunk, const T *__restrict__ skip = nullptr,
+                                                                int skip_ld = 0, int d1 = 0)
 {
     constexpr int E = RowVec<T>::E;
-    const int CT = C / E;
+    // with skip rows [B*N, d1] (row stride skip_ld): the chunks [0, col0) of every output row are written here too --
+    // the skip features, then zeros up to col0 (FeaturePropagation's torch.cat([points1, interpolated], -1), :201 / :272)
+    const int CS = skip ? col0 / E : 0;
+    const int CT = C / E + CS;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nchunk; e += (long)gridDim.x * 256) {
-        const int cc = (int)(e % CT);
+        int cc = (int)(e % CT);
         const long row = e / CT;  // b*N + n
+        if (cc < CS) {
+            float f[E];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int c = cc * E + i;
+                f[i] = c < d1 ? RowVec<T>::one(skip + row * (long)skip_ld + c) : 0.0f;
+            }
+            *reinterpret_cast<uint4 *>(out + row * (long)ld + cc * E) = RowVec<T>::pack(f);
+            continue;
+        }
+        cc -= CS;
         const long b = row / N;
         float w[K];
         float norm = 0.0f;
@@ -355,21 +370,24 @@ __global__ __launch_bounds__(256) void interpolate_bwd_csr_kernel(const T *__res
 
 template <typename T>
 int interpolate_rows(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C, int k,
-                     void *out, int ld, int col0, float *out_w, void *stream)
+                     void *out, int ld, int col0, float *out_w, void *stream, const void *skip = nullptr, int skip_ld = 0,
+                     int d1 = 0)
 {
     constexpr int E = RowVec<T>::E;
     if (!feat || !d2 || !idx || !out || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PCB_ERR_INVALID_ARG;
     if (k < 1 || k > 4 || (C % E) || (ld % E) || (col0 % E) || col0 + C > ld) return PCB_ERR_INVALID_ARG;
-    const long nchunk = (long)B * N * (C / E);
+    if (skip && (d1 < 1 || d1 > col0 || skip_ld < d1)) return PCB_ERR_INVALID_ARG;
+    const long nchunk = (long)B * N * (C / E + (skip ? col0 / E : 0));
     const dim3 grid(grid_for((size_t)nchunk));
     hipStream_t st = (hipStream_t)stream;
     const T *f = (const T *)feat;
+    const T *sk = (const T *)skip;
     T *o = (T *)out;
     switch (k) {
-        case 1: hipLaunchKernelGGL((interpolate_rows_kernel<T, 1>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
-        case 2: hipLaunchKernelGGL((interpolate_rows_kernel<T, 2>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
-        case 3: hipLaunchKernelGGL((interpolate_rows_kernel<T, 3>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
-        default: hipLaunchKernelGGL((interpolate_rows_kernel<T, 4>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk); break;
+        case 1: hipLaunchKernelGGL((interpolate_rows_kernel<T, 1>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk, sk, skip_ld, d1); break;
+        case 2: hipLaunchKernelGGL((interpolate_rows_kernel<T, 2>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk, sk, skip_ld, d1); break;
+        case 3: hipLaunchKernelGGL((interpolate_rows_kernel<T, 3>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk, sk, skip_ld, d1); break;
+        default: hipLaunchKernelGGL((interpolate_rows_kernel<T, 4>), grid, dim3(256), 0, st, f, d2, idx, N, S, C, o, ld, col0, out_w, nchunk, sk, skip_ld, d1); break;
     }
     pcb_account(sizeof(T) * (double)C * ((double)S + N) * B + 12.0 * (double)k * N * B);
     return pcb_check_launch();
@@ -402,6 +420,22 @@ extern "C" int pcb_interpolate_rows_f32(const void *feat, const float *d2, const
                                         int C, int k, void *out, int ld, int col0, float *out_w, void *stream)
 {
     return interpolate_rows<float>(feat, d2, idx, B, N, S, C, k, out, ld, col0, out_w, stream);
+}
+
+// the same with the skip features written by the same launch: out[row][0 .. d1) = skip[row][0 .. d1) (rows skip_ld
+// elements apart), out[row][d1 .. col0) = 0 -- the whole torch.cat([points1, interpolated], dim=-1) in one pass
+extern "C" int pcb_interpolate_skip_bf16(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S, int C,
+                                         int k, void *out, int ld, int col0, float *out_w, const void *skip, int skip_ld,
+                                         int d1, void *stream)
+{
+    return interpolate_rows<pcb_bf16>(feat, d2, idx, B, N, S, C, k, out, ld, col0, out_w, stream, skip, skip_ld, d1);
+}
+
+extern "C" int pcb_interpolate_rows_skip_f32(const void *feat, const float *d2, const int64_t *idx, int B, int N, int S,
+                                             int C, int k, void *out, int ld, int col0, float *out_w, const void *skip,
+                                             int skip_ld, int d1, void *stream)
+{
+    return interpolate_rows<float>(feat, d2, idx, B, N, S, C, k, out, ld, col0, out_w, stream, skip, skip_ld, d1);
 }
 
 extern "C" int pcb_interp_csr_count(const int64_t *idx, int B, int N, int S, int k, int *count, void *stream)

@@ -1270,14 +1270,20 @@ class _InterpConcat(torch.autograd.Function):
         dp = m.pad(D1)
         dev = feat.device
         out = torch.empty(B * N, dp + C, dtype=m.dtype, device=dev)
-        if skip is not None:
+        fused_skip = skip is not None and skip.dtype == m.dtype and skip.dim() == 2 and skip.stride(1) == 1
+        if skip is not None and not fused_skip:
             out[:, :D1] = skip
             if dp > D1:
                 out[:, D1:dp] = 0
         w = torch.empty(B, N, k, dtype=torch.float32, device=dev)
         with on_device(dev):
-            _launch("pcb_interpolate_bf16" if m.code == 0 else "pcb_interpolate_rows_f32", 2 * B * N * C, feat.data_ptr(),
-                    d2.data_ptr(), idx.data_ptr(), B, N, S, C, k, out.data_ptr(), dp + C, dp, w.data_ptr())
+            if fused_skip:   # the skip columns and the gap from the same launch (two strided ATen copies otherwise)
+                _launch("pcb_interpolate_skip_bf16" if m.code == 0 else "pcb_interpolate_rows_skip_f32", 2 * B * N * C,
+                        feat.data_ptr(), d2.data_ptr(), idx.data_ptr(), B, N, S, C, k, out.data_ptr(), dp + C, dp, w.data_ptr(),
+                        skip.data_ptr(), skip.stride(0), D1)
+            else:
+                _launch("pcb_interpolate_bf16" if m.code == 0 else "pcb_interpolate_rows_f32", 2 * B * N * C, feat.data_ptr(),
+                        d2.data_ptr(), idx.data_ptr(), B, N, S, C, k, out.data_ptr(), dp + C, dp, w.data_ptr())
         ctx.save_for_backward(idx, w, offsets, entries)
         ctx.shape = (B, N, S, C, k, D1, dp, m)
         return out
