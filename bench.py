@@ -847,6 +847,33 @@ def main():
         dist.destroy_process_group()
 
 
+def knn_roofline(B, N, device, D=64, k=20):
+    """cfg3's dominant kernel: the feature-space kNN call of an EdgeConv block (models/DGCNN.py:49-70 at D = 64, three per
+    step).  Its pair products run on the bf16 matrix core (three MFMAs per 16 channels of the two-term split) and its
+    selection on the vector pipe; priced against the dense bf16 MFMA peak: algorithmic work = the 2 N^2 D flop per scene of
+    the distance matrix, duration = HIP events on the launch stream around 10 calls on BatchNorm+LeakyReLU-like rows."""
+    from pointcloud_bridge_amd import ops
+    torch.manual_seed(3)
+    x = torch.nn.functional.leaky_relu(torch.randn(B, N, D, device=device), 0.2).contiguous()
+    for _ in range(3):
+        ops.knn(x, k)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(10):
+        ops.knn(x, k)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / 10 * 1e3
+    flops = 2.0 * B * N * N * D
+    peak = 2500.0   # dense bf16 MFMA, TFLOP/s (MI355X_MICROARCH.md)
+    return {"bound": "mfma", "kernel": "pcb_knn_screened (knn_screen_kernel<64,20,24> + split / norms / exact fallback)",
+            "achieved": flops / (us * 1e-6) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / (us * 1e-6) / 1e12 / peak,
+            "traffic": None, "avg_call_us": us,
+            "note": "distance-matrix flop (2 N^2 D per scene) per call; the kernel issues 3x that on the bf16 matrix core and is "
+                    "bound by the vector instructions of its top-k selection (DESIGN.md section 6), not by the products"}
+
+
 def extras(args, device):
     """Short runs (a few steps each) of the other configurations SURVEY section 8(d) names, so that the
     driver's one bench line carries them: cfg3 DGCNN, cfg4's network BridgeSeg, the fp32 parity mode
@@ -889,6 +916,8 @@ def extras(args, device):
             if launches:
                 entry["gemm_nt_GBps"] = res["nt_bytes"] / (res["nt_ms"] * 1e-3) / 1e9
                 entry["gemm_nt_avg_us"] = res["nt_ms"] / launches * 1e3
+            if kw["model_name"] == "dgcnn" and not kw.get("graph"):
+                entry["roofline"] = knn_roofline(kw["B"], kw["N"], device)
             out[name] = entry
             del run
         except BaseException as e:  # an extra must never cost the headline line

@@ -27,6 +27,21 @@ class _SamplingPrefetchMixin:
     # (first top-level child module of the decoder: the parameters in front of it form the encoder's gradient bucket)
     decoder_first = "fp3"
 
+    @property
+    def sampling(self):
+        """This model's pointnet2_utils.SamplingState: its prefetched pyramid, parked neighbour tables, installed static
+        pipeline and scene shard.  Current for the duration of every call of the model (see __call__)."""
+        st = self.__dict__.get("_sampling_state")
+        if st is None:
+            from .pointnet2_utils import SamplingState
+            st = self.__dict__["_sampling_state"] = SamplingState()
+        return st
+
+    def __call__(self, *args, **kwargs):
+        from .pointnet2_utils import sampling_scope
+        with sampling_scope(self.sampling):
+            return super().__call__(*args, **kwargs)
+
     def _cut(self, *tensors):
         return tensors if self.decoder_cut is None else tuple(self.decoder_cut(*tensors))
 
@@ -38,7 +53,9 @@ class _SamplingPrefetchMixin:
                  for m in sas]
         k = 4 if hasattr(self.fp1, "attention") else 3   # EnhancedFeaturePropagation uses 4 neighbours (:256)
         # decoder stages: fp3 level 2 <- 3, fp2 level 1 <- 2, fp1 level 0 <- 1
-        prefetch_sampling(xyz.contiguous(), [m.npoint for m in sas], balls, [(2, 3, k), (1, 2, k), (0, 1, k)])
+        from .pointnet2_utils import sampling_scope
+        with sampling_scope(self.sampling):
+            prefetch_sampling(xyz.contiguous(), [m.npoint for m in sas], balls, [(2, 3, k), (1, 2, k), (0, 1, k)])
 
     def static_sampling(self, xyz):
         """A pointnet2_utils.StaticSampling pipeline for steps replayed from a hipGraph: the same coordinate-only
@@ -49,7 +66,9 @@ class _SamplingPrefetchMixin:
         balls = [((m.radius_list, m.nsample_list) if hasattr(m, "radius_list") else ([m.radius], [m.nsample]))
                  for m in sas]
         k = 4 if hasattr(self.fp1, "attention") else 3
-        return StaticSampling(xyz, [m.npoint for m in sas], balls, [(2, 3, k), (1, 2, k), (0, 1, k)])
+        from .pointnet2_utils import sampling_scope
+        with sampling_scope(self.sampling):
+            return StaticSampling(xyz, [m.npoint for m in sas], balls, [(2, 3, k), (1, 2, k), (0, 1, k)])
 
     def set_next(self, xyz):
         """Pipelined inference: the coordinates of the batch that FOLLOWS the next forward call.  That
@@ -61,8 +80,8 @@ class _SamplingPrefetchMixin:
         if self._next_xyz is not None:
             nxt, self._next_xyz = self._next_xyz, None
             from . import pointnet2_utils as pu
-            if pu._static is not None:      # a captured pass: into the pipeline's staging set, on its side stream
-                pu._static.compute_beside(nxt.contiguous())
+            if pu.static_sampling() is not None:      # a captured pass: into the pipeline's staging set, on its side stream
+                pu.static_sampling().compute_beside(nxt.contiguous())
             else:
                 self.prefetch(nxt)
 

@@ -15,6 +15,7 @@ transposed views of channels-last storage.
 GPU only: CPU tensors raise (there is no fallback path).
 """
 import os
+import threading
 import weakref
 
 import torch
@@ -37,7 +38,45 @@ def index_points(points, idx):
     return ops.gather_rows(points, idx)
 
 
-_scene_shard = (0, 1)
+class SamplingState:
+    """What a forward pass may pick up instead of computing it -- the prefetched FPS pyramid, parked ball-query / k-NN /
+    inverted-index results and their double-set buffers, an installed StaticSampling pipeline, the scene shard of a
+    strong-scaling run.  Every container model owns one (containers._SamplingPrefetchMixin.sampling) and makes it the
+    current one for the duration of its calls (`sampling_scope`, thread-local), so two models in one process do not
+    see each other's prefetches; the functions of this module called directly use the process default."""
+
+    def __init__(self):
+        self.prefetched = {}
+        self.parked = {}   # coordinate-only results of prefetch_sampling other than the FPS pyramid: key -> (tensors, event, parity, source)
+        self.owned = {}    # their storage: (kind, ordinal, parity) -> tensors, allocated once on the main stream
+        self.parity = 0
+        self.static = None
+        self.scene_shard = None   # (rank, world) of this model's batches; None: the process default (set_scene_shard)
+
+
+_default_state = SamplingState()
+_tls = threading.local()
+_process_shard = (0, 1)
+
+
+def _st():
+    return getattr(_tls, "state", None) or _default_state
+
+
+class sampling_scope:
+    """with sampling_scope(state): the module's lookups and prefetches use `state` (nests; per thread)."""
+
+    def __init__(self, state):
+        self.state = state
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "state", None)
+        _tls.state = self.state
+        return self.state
+
+    def __exit__(self, *exc):
+        _tls.state = self.prev
+        return False
 
 
 def set_scene_shard(rank, world):
@@ -45,14 +84,21 @@ def set_scene_shard(rank, world):
     every rank draws the start indices of the whole global batch from its CPU generator -- seeded
     identically on all ranks -- and keeps the entries of its own scenes.  The sharded run then
     consumes the reference's RNG stream (pointnet2_utils.py:69) exactly like a single process over the
-    global batch, so its samples, and with SyncBatchNorm its step, equal the single-process step."""
-    global _scene_shard
+    global batch, so its samples, and with SyncBatchNorm its step, equal the single-process step.
+    This sets the PROCESS default (one process = one rank); a model can carry its own in
+    `model.sampling.scene_shard`, and farthest_point_sample takes `shard=` explicitly."""
+    global _process_shard
     if not 0 <= rank < world:
         raise ValueError(f"rank {rank} outside world {world}")
-    _scene_shard = (int(rank), int(world))
+    _process_shard = (int(rank), int(world))
 
 
-def farthest_point_sample(xyz, npoint):
+def scene_shard(state=None):
+    st = state if state is not None else _st()
+    return st.scene_shard if st.scene_shard is not None else _process_shard
+
+
+def farthest_point_sample(xyz, npoint, shard=None):
     """xyz [B,N,3] -> [B,npoint] int64 (reference :63-80).
 
     Consumes exactly one torch.randint(0, N, (B,)) from the CPU default generator, like the
@@ -60,7 +106,7 @@ def farthest_point_sample(xyz, npoint):
     global batches)."""
     B, N, _ = xyz.shape
     ops._need_cuda(xyz)  # GPU only: fail here, before any staging copy
-    rank, world = _scene_shard
+    rank, world = shard if shard is not None else scene_shard()
     start = torch.randint(0, N, (B * world,), dtype=torch.long)[rank * B:(rank + 1) * B]
     # pinned staging + asynchronous copy: a pageable .to(device) would stall the host until the
     # stream has drained, three times per forward pass
@@ -75,7 +121,6 @@ def farthest_point_sample(xyz, npoint):
 # preparing the next batch (train_MulSca_PN2.py:92-106).  Results and RNG consumption are unchanged:
 # the start indices are drawn from the CPU generator in the same order, just earlier.
 # ---------------------------------------------------------------------------------------------
-_prefetched = {}
 _side_stream = None
 
 
@@ -107,7 +152,8 @@ class _Source:
 
 def _drop_dead():
     """Forget everything parked for coordinate tensors that no longer exist."""
-    for table in (_prefetched, _parked):
+    st = _st()
+    for table in (st.prefetched, st.parked):
         for k in [k for k, v in table.items() if not v[-1].alive()]:
             del table[k]
 
@@ -137,31 +183,31 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
     _sample, and picked up by _ball_indices / _nearest.  Contract: a parked result (and whatever
     autograd saved of it) is valid until the SECOND prefetch after the one that produced it, i.e. for
     the usual forward -> prefetch -> backward -> step loop and for pipelined inference."""
-    global _parity
+    st = _st()
     side_stream(xyz.device)
     main = torch.cuda.current_stream()
     _side_stream.wait_stream(main)
     src = _Source(xyz)
-    _prefetched.clear()
+    st.prefetched.clear()
     # entries of the batch in flight stay (a pipelined inference pass starts this prefetch before its
     # own decoder has taken its k-NN); their set of buffers is not the one written now
-    for stale in [k for k, v in _parked.items() if v[2] != _parity]:
-        del _parked[stale]
-    _parity ^= 1
+    for stale in [k for k, v in st.parked.items() if v[2] != st.parity]:
+        del st.parked[stale]
+    st.parity ^= 1
     cur = xyz
     levels = [xyz]
 
     def park(key, res):
-        slot = (key[0], sum(1 for v in _parked.values() if v[2] == _parity), _parity)
-        held = _owned.get(slot)
+        slot = (key[0], sum(1 for v in st.parked.values() if v[2] == st.parity), st.parity)
+        held = st.owned.get(slot)
         if held is None or any(h.shape != r.shape or h.dtype != r.dtype for h, r in zip(held, res)):
             with torch.cuda.stream(main):  # blocks of the main stream's pool, for good
-                held = _owned[slot] = tuple(torch.empty_like(r) for r in res)
+                held = st.owned[slot] = tuple(torch.empty_like(r) for r in res)
         for h, r in zip(held, res):
             h.copy_(r)
         ev = torch.cuda.Event()
         ev.record(_side_stream)
-        _parked[key] = (held, ev, _parity, src)
+        st.parked[key] = (held, ev, st.parity, src)
 
     with torch.cuda.stream(_side_stream):
         for l, npoint in enumerate(npoints):
@@ -169,7 +215,7 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
             new_xyz = index_points(cur, idx)
             ev = torch.cuda.Event()
             ev.record(_side_stream)
-            _prefetched[_key(cur, npoint)] = (idx, new_xyz, ev, src)
+            st.prefetched[_key(cur, npoint)] = (idx, new_xyz, ev, src)
             if balls is not None and balls[l] is not None:
                 radii, nsamples = balls[l]
                 park(_ball_key(radii, nsamples, cur, new_xyz), _ball_indices_now(radii, nsamples, cur, new_xyz))
@@ -180,7 +226,7 @@ def prefetch_sampling(xyz, npoints, balls=None, propagation=None):
             park(nn_key, ops.three_nn(levels[fine], levels[coarse], k))
             if torch.is_grad_enabled():
                 # the inverted index the interpolation's backward pass reduces over
-                held_idx = _parked[nn_key][0][1]
+                held_idx = st.parked[nn_key][0][1]
                 park(("csr", held_idx.data_ptr()), rowmlp.build_interp_csr(held_idx, levels[coarse].shape[1]))
         ev = torch.cuda.Event()
         ev.record(_side_stream)
@@ -215,6 +261,7 @@ class StaticSampling:
         # computed with the pyramid, staged and committed like the rest, found by lookup_job(key, cloud)
         self.jobs = list(jobs or ())
         self.extra = {}   # key -> (live tensors, staging tensors), allocated at the first compute()
+        self.state = _st()  # the SamplingState this pipeline serves (a model's own when built by model.static_sampling)
         self._pending = []  # (staging, result) pairs of the compute() under way
         n_in = N
         # FPS start indices of all levels: ONE device buffer, filled by one asynchronous copy per draw() from a ring of
@@ -244,7 +291,7 @@ class StaticSampling:
         else:
             self._pin_events[i].synchronize()   # the copy that last read this slot has executed (normally long ago)
         host = self._pinned[i]
-        rank, world = _scene_shard
+        rank, world = scene_shard(self.state)
         for l, lv in enumerate(self.levels):
             B = host.shape[1]
             host[l].copy_(torch.randint(0, lv["n_in"], (B * world,), dtype=torch.long)[rank * B:(rank + 1) * B])
@@ -379,27 +426,37 @@ class StaticSampling:
         return None if held is None else held[0]
 
 
-_static = None
+_static_states = []   # the states a pipeline is installed in (set_static_sampling(None) removes them all)
 
 
 def set_static_sampling(pipeline):
-    """Install (or remove, with None) a StaticSampling pipeline for subsequent forward passes."""
-    global _static
-    _static = pipeline
+    """Install a StaticSampling pipeline for subsequent forward passes -- in the SamplingState it was built under
+    (model.static_sampling(...) builds it under the model's own) -- or, with None, remove every installed one."""
+    if pipeline is None:
+        for st in _static_states:
+            st.static = None
+        _static_states.clear()
+        _st().static = None
+        return
+    st = pipeline.state
+    st.static = pipeline
+    if st not in _static_states:
+        _static_states.append(st)
 
 
 def static_sampling():
-    return _static
+    return _st().static
 
 
 def _sample(xyz, npoint):
     """(fps_idx, new_xyz) for this level: static buffers of a captured step, else the prefetched
     pair if there is one, else computed now."""
-    if _static is not None:
-        hit = _static.lookup(xyz, npoint)
+    st = _st()
+    if st.static is not None:
+        hit = st.static.lookup(xyz, npoint)
         if hit is not None:
             return hit
-    hit = _prefetched.pop(_key(xyz, npoint), None) if _prefetched else None
+    hit = st.prefetched.pop(_key(xyz, npoint), None) if st.prefetched else None
     if hit is not None and not (hit[3].alive() and hit[3].matches(xyz)):
         _drop_dead()
         hit = None
@@ -414,15 +471,10 @@ def _sample(xyz, npoint):
     return idx, new_xyz
 
 
-_parked = {}  # coordinate-only results of prefetch_sampling other than the FPS pyramid: key -> (tensors, event)
-_owned = {}   # their storage: (kind, ordinal, parity) -> tensors, allocated once on the main stream
-_parity = 0
-
-
 def _take_parked(key, xyz=None):
     """The parked result for `key`, if its prefetch was issued for a coordinate tensor that is still
     alive (and, when the key is built from `xyz`'s address, for that very tensor)."""
-    hit = _parked.pop(key, None)
+    hit = _st().parked.pop(key, None)
     if hit is None:
         return None
     res, ev, _, src = hit
@@ -445,21 +497,23 @@ def _ball_indices_now(radii, nsamples, xyz, new_xyz):
 
 def _ball_indices(radii, nsamples, xyz, new_xyz):
     """Ball-query indices of every scale of a set abstraction: parked by prefetch_sampling or computed now."""
-    if _static is not None:
-        hit = _static.lookup_ball(radii, nsamples, xyz, new_xyz)
+    st = _st()
+    if st.static is not None:
+        hit = st.static.lookup_ball(radii, nsamples, xyz, new_xyz)
         if hit is not None:
             return hit
-    hit = _take_parked(_ball_key(radii, nsamples, xyz, new_xyz), xyz) if _parked else None
+    hit = _take_parked(_ball_key(radii, nsamples, xyz, new_xyz), xyz) if st.parked else None
     return hit if hit is not None else _ball_indices_now(radii, nsamples, xyz, new_xyz)
 
 
 def _nearest(xyz1, xyz2, k):
     """(d2, idx) of the k nearest xyz2 points of every xyz1 point: parked by prefetch_sampling or computed now."""
-    if _static is not None:
-        hit = _static.lookup_extra("nn", xyz1, xyz2, k)
+    st = _st()
+    if st.static is not None:
+        hit = st.static.lookup_extra("nn", xyz1, xyz2, k)
         if hit is not None:
             return hit
-    hit = _take_parked(("nn", xyz1.data_ptr(), xyz2.data_ptr(), int(k)), xyz1) if _parked else None
+    hit = _take_parked(("nn", xyz1.data_ptr(), xyz2.data_ptr(), int(k)), xyz1) if st.parked else None
     return hit if hit is not None else ops.three_nn(xyz1, xyz2, k)
 
 
@@ -674,9 +728,10 @@ def _propagate_rows(xyz1, xyz2, points1, points2, k):
     S, C = xyz2.shape[1], points2.shape[1]
     if S > 1 and C % rowmlp.mode().q == 0:
         d2, idx = _nearest(xyz1, xyz2, k)
-        csr = _static.lookup_extra("csr", xyz1, xyz2, k) if _static is not None else None
+        st = _st()
+        csr = st.static.lookup_extra("csr", xyz1, xyz2, k) if st.static is not None else None
         if csr is None:
-            csr = _take_parked(("csr", idx.data_ptr())) if _parked else None
+            csr = _take_parked(("csr", idx.data_ptr())) if st.parked else None
         skip = None if points1 is None else _channels_last(points1).reshape(B * N, -1)
         return rowmlp.interpolate_concat(skip, _channels_last(points2), d2, idx, csr)
     x = _interpolate(xyz1, xyz2, points2, k)

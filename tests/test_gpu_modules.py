@@ -206,7 +206,8 @@ def test_sampling_prefetch_gives_identical_results(mpu):
     assert torch.equal(inline, pre)
     assert torch.equal(after_inline, after_pre)          # same number of CPU draws consumed
     assert rel_err(pre, g["logits_eval"]) < REL
-    assert len(mpu._prefetched) == 0                     # every level was picked up
+    assert len(model.sampling.prefetched) == 0           # every level was picked up (the model's own SamplingState)
+    assert len(mpu._default_state.prefetched) == 0       # ... and nothing leaked into the process default
 
 
 def test_pipelined_inference_gives_identical_results(mpu):

@@ -420,3 +420,46 @@ def test_screened_knn_small_cloud_against_the_oracle():
     g = torch.Generator().manual_seed(5)
     x = torch.nn.functional.leaky_relu(torch.randn(2, 640, 64, generator=g), 0.2)
     assert np.array_equal(ops.knn(x.cuda(), 20).cpu().numpy(), orc.knn(x.numpy(), 20))
+
+
+def test_two_models_keep_their_own_prefetches():
+    """the prefetch tables belong to the model.  Model A prefetches its next batch, model B prefetches and
+    runs in between (which used to clear A's pending pyramid: A then sampled inline and consumed the CPU generator a second
+    time), then A runs: bit-identical to A alone, same number of CPU draws, both models' tables empty afterwards."""
+    from pointcloud_bridge_amd.models import pointnet2_utils as pu
+    a, b = _model(1).eval(), _model(2).eval()
+    xa, ca, _ = _batch(11)
+    xb, cb, _ = _batch(12)
+    with torch.no_grad():
+        torch.manual_seed(5)
+        a.prefetch(xa)
+        alone = a(xa, ca)
+        after_alone = torch.rand(1)
+        torch.manual_seed(5)
+        a.prefetch(xa)
+        state = torch.get_rng_state()          # B's own draws must not count against A's stream in this comparison
+        b.prefetch(xb)
+        b(xb, cb)
+        torch.set_rng_state(state)
+        mixed = a(xa, ca)
+        after_mixed = torch.rand(1)
+    assert torch.equal(alone, mixed)
+    assert torch.equal(after_alone, after_mixed)
+    assert a.sampling is not b.sampling
+    assert not a.sampling.prefetched and not b.sampling.prefetched and not pu._default_state.prefetched
+
+
+def test_scene_shard_is_a_property_of_the_model_or_an_argument():
+    from pointcloud_bridge_amd.models import pointnet2_utils as pu
+    xyz, _, _ = _batch(4, B=2, N=512)
+    torch.manual_seed(3)
+    whole = pu.farthest_point_sample(torch.cat([xyz, xyz]), 64)           # a global batch of 4 scenes
+    torch.manual_seed(3)
+    second = pu.farthest_point_sample(xyz, 64, shard=(1, 2))              # its second half on rank 1 of 2: same draws
+    assert torch.equal(second, whole[2:])
+    m = _model(1)
+    m.sampling.scene_shard = (1, 2)
+    with pu.sampling_scope(m.sampling):
+        torch.manual_seed(3)
+        assert torch.equal(pu.farthest_point_sample(xyz, 64), whole[2:])
+    assert pu.scene_shard() == (0, 1)                                     # the process default is untouched
