@@ -82,7 +82,7 @@ def kernel_timer_read(category):
 _background = None  # (event, busy_cus)
 _hint_now = 0
 _capture_calls = 0
-_GRAPH_HINT_CALLS = int(os.environ.get("PCB_GRAPH_HINT_CALLS", "8"))
+_GRAPH_HINT_CALLS = int(os.environ.get("PCB_GRAPH_HINT_CALLS", "10"))
 _capture_limit = _GRAPH_HINT_CALLS
 
 
@@ -104,7 +104,8 @@ def apply_concurrency_hint():
             # lasts ~1.5 ms of a 5 ms backward pass.  Holding the hint for the whole step costs more than it
             # saves (measured: 12.4 against 10.6 ms/step, round 1); holding it for the first n stack calls after
             # the fork -- the backward passes that do run beside the pyramid -- pays: PN2-MSG, one box,
-            # n = 0 / 4 / 8 / 12 / 20: 7.63 / 7.59 / 7.46 / 7.47 / 7.57 ms per step (PCB_GRAPH_HINT_CALLS, default 8).
+            # n = 0 / 4 / 8 / 12 / 20: 7.63 / 7.59 / 7.46 / 7.47 / 7.57 ms per step (round 2); round 3 (fused layer backward): n = 0 / 4 / 6 / 8 / 10 /
+            # 12 / 14 / 18: 6.95 / 6.94 / 6.81 / 6.68 / 6.65 / 6.67 / 6.68 / 6.76 (PCB_GRAPH_HINT_CALLS, default 10).
             global _capture_calls
             _capture_calls += 1
             want = _background[1] if _capture_calls <= _capture_limit else 0
