@@ -371,6 +371,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_screen_kernel(const float *__
     constexpr int kTC = DP <= 64 ? 64 : 32;      // candidates per LDS stage: two workgroups per CU (80 KB each)
     constexpr int T = kTC / 32;                  // tiles per stage
     constexpr int QCAP = 32;
+    constexpr int kMergeTiles = 32;  // tiles between two hand-overs of the half-lane lists (8 / 16 / 32 / 64: 603 / 583 / 582 / 580 us)
     constexpr int NV = kTC * DP / 8 / kThreads;  // 16-byte loads per thread, stage and half (hi / lo)
     static_assert(NV >= 1, "stage smaller than the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned short tiles[2][2][kTC * LD];   // [buffer][hi | lo]
@@ -424,8 +425,28 @@ __global__ __launch_bounds__(kThreads, 2) void knn_screen_kernel(const float *__
         }
         qcnt = 0;
     };
+    // Lanes n and n+32 serve the same query on disjoint halves of the candidates.  Every kMergeTiles tiles the upper
+    // lane hands its list to the lower one (which then holds the best KS of everything seen so far), empties its own and
+    // keeps the merged list's last entry as a CAP: a key above it cannot be among the best KS of the union, whichever
+    // half it comes from.  The filter threshold of both lanes is then the union's KS-th key instead of a half's -- about
+    // half as many candidates pass, half as many queue entries to insert -- and the two lists never share an entry.
+    uint32_t cap = 0xffffffffu;
     // keys up to this value may still enter the list (finite: a candidate beyond the cloud has an infinite key)
-    auto threshold = [&]() { return unsortable(min(bd[KS - 1] | imask, 0xff7fffffu)); };
+    auto threshold = [&]() { return unsortable(min(min(bd[KS - 1], cap) | imask, 0xff7fffffu)); };
+    auto merge_halves = [&]() {
+        uint32_t od[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) od[s] = (uint32_t)__shfl((int)bd[s], lane ^ 32);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            od[s] = h ? 0xffffffffu : od[s];   // the upper lane inserts neutral words into its emptied list
+            bd[s] = h ? 0xffffffffu : bd[s];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) insert_packed<KS>(bd, od[s]);
+        const uint32_t merged_worst = (uint32_t)__shfl((int)bd[KS - 1], lane & 31);
+        cap = h ? merged_worst : cap;
+    };
 
     uint4 pre[2][NV];
     float pre_n = 0.0f;
@@ -481,11 +502,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_screen_kernel(const float *__
             const float cnv[4] = {cn4[g].x, cn4[g].y, cn4[g].z, cn4[g].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-#ifdef KNN_EXP_NOMFMA
-                if (false) {
-#else
                 if (has_next) {
-#endif
 #pragma unroll
                     for (int m = (g * 4 + j) * M / 16; m < (g * 4 + j + 1) * M / 16; ++m) {
                         const int s = m / 3;
@@ -494,11 +511,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_screen_kernel(const float *__
                     }
                 }
                 const float v = __fadd_rn(__fmaf_rn(-2.0f, acc[g * 4 + j], qnorm), cnv[j]);   // the key
-#ifdef KNN_EXP_NOPUSH
-                if (v <= thr && cbase < 64) {
-#else
                 if (v <= thr) {
-#endif
                     qk[qcnt][t] = (sortable(v) & ~imask) | (uint32_t)(cbase + 8 * g + 4 * h + j);
                     ++qcnt;
                 }
@@ -532,10 +545,6 @@ __global__ __launch_bounds__(kThreads, 2) void knn_screen_kernel(const float *__
     // the selection of the tile before), so the next stage may be stashed into the other buffer and its first tile's
     // products run behind the last selection; the key terms of the last tile are read after the barrier, hence the ring.
     int buf = 0, ring = 0;
-#ifdef KNN_EXP_TIMING
-    unsigned long long tm[5] = {0, 0, 0, 0, 0};
-    unsigned long long c0 = __builtin_amdgcn_s_memtime();
-#endif
     for (int base = 0; base < N; base += kTC, buf ^= 1, ring = ring == 2 ? 0 : ring + 1) {
         const bool more = base + kTC < N;
 #pragma unroll
@@ -544,39 +553,16 @@ __global__ __launch_bounds__(kThreads, 2) void knn_screen_kernel(const float *__
                  &tiles[buf][1][(tt + 1) * 32 * LD], nacc);
             acc = nacc;
         }
-#ifdef KNN_EXP_TIMING
-        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-        tm[0] += c1 - c0;
-#endif
         if (more) stash(buf ^ 1, ring == 2 ? 0 : ring + 1);
-#ifdef KNN_EXP_TIMING
-        __builtin_amdgcn_s_waitcnt(0);
-        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
-        tm[1] += c2 - c1;
-#endif
-#ifndef KNN_EXPERIMENT_NO_BARRIER
         __syncthreads();
-#endif
-#ifdef KNN_EXP_TIMING
-        const unsigned long long c3 = __builtin_amdgcn_s_memtime();
-        tm[2] += c3 - c2;
-#endif
         if (base + 2 * kTC < N) fetch(base + 2 * kTC);
-#ifdef KNN_EXP_TIMING
-        const unsigned long long c4 = __builtin_amdgcn_s_memtime();
-        tm[3] += c4 - c3;
-#endif
         step(acc, &cnrms[ring][(T - 1) * 32], base + (T - 1) * 32, more, &tiles[buf ^ 1][0][0], &tiles[buf ^ 1][1][0], nacc);
         acc = nacc;
-#ifdef KNN_EXP_TIMING
-        c0 = __builtin_amdgcn_s_memtime();
-        tm[4] += c0 - c4;
-#endif
+        if (((base / kTC + 1) % (kMergeTiles / T)) == 0 && more) {   // wave-uniform; queues empty before the hand-over
+            drain();
+            merge_halves();
+        }
     }
-#ifdef KNN_EXP_TIMING
-    if (lin == 37 && lane == 0)
-        for (int i = 0; i < 5; ++i) qtk[(size_t)N - 64 + wave * 8 + i] = (float)tm[i];
-#endif
     drain();
 
     // lanes n and n+32 saw disjoint halves of the candidates: both end up with the KS smallest of the union
