@@ -11,7 +11,7 @@ python tools/nt_bench.py gpurun_out/round/tn_trace.txt > gpurun_out/round/nt_ben
 python tools/fused_bench.py gpurun_out/round/tn_trace.txt > gpurun_out/round/fused_bench.log 2>&1
 python tools/knn_screen_bench.py > gpurun_out/round/knn_screen_bench.log 2>&1
 for n in pn2_msg_bf16 pn2_msg_bf16_single_stream pn2_msg_fp32 pn2_msg_bf16_infer dgcnn_bf16 bridgeseg_bf16 pn2_msg_bf16_graph; do
-  python tools/prof_categories.py gpurun_out/round/$n 13 > gpurun_out/round/${n}_categories.txt 2>&1
+  python tools/prof_categories.py gpurun_out/round/$n 0 > gpurun_out/round/${n}_categories.txt 2>&1
 done
 rm -rf gpurun_out/round/*/p_kernel_trace.csv gpurun_out/round/pmc_*/p*_counter_collection.csv
 tail -3 gpurun_out/round_stats.log; tail -1 gpurun_out/round/nt_bench.log; tail -1 gpurun_out/round/tn_bench.log
