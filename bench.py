@@ -921,6 +921,12 @@ def extras(args, device):
             if launches:
                 entry["gemm_nt_GBps"] = res["nt_bytes"] / (res["nt_ms"] * 1e-3) / 1e9
                 entry["gemm_nt_avg_us"] = res["nt_ms"] / launches * 1e3
+                if kw["model_name"] != "dgcnn":   # (cfg3's dominant kernel is its kNN: knn_roofline below)
+                    entry["roofline"] = {"bound": "hbm", "kernel": ROOFLINE_KERNEL, "achieved": entry["gemm_nt_GBps"],
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": entry["gemm_nt_GBps"] / HBM_PEAK_GBS,
+                                         "traffic": None, "launches": launches,
+                                         "note": "HIP events around the family's launches in the timed region of this run "
+                                                 "(eager step, GEMMs of concurrent chains share the chip)"}
             if kw["model_name"] == "dgcnn" and not kw.get("graph"):
                 entry["roofline"] = knn_roofline(kw["B"], kw["N"], device)
             out[name] = entry
