@@ -1299,6 +1299,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void bwd_fused_kern
     long tile = blockIdx.x;
     if (tile < tiles) fetch(tile);
     __syncthreads();  // constants, W^T
+    // eight-wave form: a wave's W^T fragments of the dx phase do not change from tile to tile -- read once (TC / 16 steps x
+    // XD tiles x 4 registers = 64), which halves the LDS traffic of that phase (it is bound by it: 2 KB per MFMA and wave)
+    constexpr bool kWreg = false && WAVES == 8 && XD == 1;   // (measured: 64 more registers spill -- 29-51 VGPRs -- at 256 x 128)
+    bf16x8 wfrag[kWreg ? TC / 16 : 1];
+    if (kWreg) {
+#pragma unroll
+        for (int ks = 0; ks < TC / 16; ++ks)
+            wfrag[ks] = *reinterpret_cast<const bf16x8 *>(&Ws[(wna * (TK / WNA) + (lane & 31)) * LDW + ks * 16 + (lane >> 5) * 8]);
+    }
     for (; tile < tiles; tile += gridDim.x) {
         const long m0 = tile * BF_BM;
         {   // park: both tiles, transformed
@@ -1314,6 +1323,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void bwd_fused_kern
                 *reinterpret_cast<uint4 *>(&Xs[(rowk + RPK * i) * LDK + chk * 8]) = finish_with<PRO_BNACT>(rx[i], kx, x_slope);
         }
         __syncthreads();
+        // eight-wave form (one workgroup per CU: nobody hides a reload's round trip): the raw rows below stay in registers
+        // for the sums of the epilogue -- two chunks per thread
+        uint4 ykeep[WAVES == 8 ? NK : 1];
+        if (WAVES == 8) {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) ykeep[i] = rx[i].v0;
+        }
         if (tile + gridDim.x < tiles) fetch(tile + gridDim.x);   // the next tile's loads fly under everything below
         // dW += dy^T x'   (contraction over the tile's 64 rows)
         typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
@@ -1352,7 +1368,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void bwd_fused_kern
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Dy[(wma * 32 + (lane & 31)) * LDC + kk]);
 #pragma unroll
             for (int j = 0; j < XD; ++j) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[(wna * (TK / WNA) + j * 32 + (lane & 31)) * LDW + kk]);
+                const bf16x8 b = kWreg ? wfrag[ks]
+                                       : *reinterpret_cast<const bf16x8 *>(&Ws[(wna * (TK / WNA) + j * 32 + (lane & 31)) * LDW + kk]);
                 accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, accx[j], 0, 0, 0);
             }
         }
@@ -1372,7 +1389,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void bwd_fused_kern
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
                 const long r = m0 + rowk + RPK * i;
-                yraw[i] = *reinterpret_cast<const uint4 *>(X.a0 + (r < R ? r : R - 1) * X.ld + (chk * 8 < K ? chk * 8 : 0));
+                if (WAVES == 8) yraw[i] = ykeep[i];
+                else yraw[i] = *reinterpret_cast<const uint4 *>(X.a0 + (r < R ? r : R - 1) * X.ld + (chk * 8 < K ? chk * 8 : 0));
             }
             float sc[8], sh[8], mu[8], is[8];
             ConstsLds<PRO_BNACT>::rd8(cstX + chk * 8, sc);
