@@ -241,8 +241,8 @@ int pcb_nbr_mlp_backward_apply(const float *base, const float *rel, long P, int 
  * (N = 3..16 output columns: no MFMA tile to fill; they are HBM streams of 4*(Ci+Co) bytes per row).
  *   pcb_rows_linear_f32        y [P,Co] = x [P,Ci] . w[Co,Ci]^T + bias[Co] (bias may be NULL)
  *   pcb_rows_linear_dgrad_f32  dx [P,Ci] = dy [P,Co] . w[Co,Ci]
- *   pcb_rows_linear_wgrad_f32  partials [parts][Co][Ci+1]: per-block sums of dy^T x, last column = sum dy
- *                              (bias gradient); parts = pcb_rows_linear_wgrad_partials(P); the caller adds
+ *   pcb_rows_linear_wgrad_f32  partials [parts][Co*Ci + Co]: per-block sums of dy^T x as a [Co][Ci] block, then
+ *                              the Co sums of dy (bias gradient); parts = pcb_rows_linear_wgrad_partials(P); the caller adds
  *                              the slabs.  1 <= Ci, Co <= 64.
  */
 int pcb_rows_linear_f32(const float *x, const float *w, const float *bias, long P, int Ci, int Co, float *y,

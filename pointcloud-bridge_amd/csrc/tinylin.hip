@@ -57,8 +57,8 @@ __global__ __launch_bounds__(kThreads) void rows_linear_kernel(const float *__re
     }
 }
 
-// part[block][o][i] = sum over the block's rows of dy[r][o] * x[r][i]   (i < Ci), and column Ci holds
-// sum dy[r][o] (the bias gradient).  Every block writes its whole slab.
+// part[block] = { dW[o][i] = sum over the block's rows of dy[r][o] * x[r][i]  (Co*Ci floats) | db[o] = sum dy[r][o] (Co floats) }.
+// Every block writes its whole slab.
 __global__ __launch_bounds__(kThreads) void rows_linear_wgrad_kernel(const float *__restrict__ dy,
                                                                      const float *__restrict__ x, long P, int Ci,
                                                                      int Co, float *__restrict__ part)
@@ -93,7 +93,11 @@ __global__ __launch_bounds__(kThreads) void rows_linear_wgrad_kernel(const float
 #pragma unroll
     for (int s = 0; s < (int)(sizeof(acc) / sizeof(float)); ++s) {
         const int e = s * kThreads + threadIdx.x;
-        if (e < entries) part[(long)blockIdx.x * entries + e] = acc[s];
+        if (e < entries) {
+            // slab layout [Co*Ci weight entries | Co bias entries]: both gradients are contiguous blocks of the summed slab
+            const int o = e / (Ci + 1), i = e - o * (Ci + 1);
+            part[(long)blockIdx.x * entries + (i < Ci ? o * Ci + i : Co * Ci + o)] = acc[s];
+        }
     }
 }
 

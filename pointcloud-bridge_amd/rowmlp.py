@@ -1373,7 +1373,7 @@ class _BNActRows(torch.autograd.Function):
             else:
                 _launch("pcb_bn_act_bwd_" + m.sfx, R * C, gb.data_ptr(), y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
                         stats[4].data_ptr(), stats[5].data_ptr(), R, C, act, training, bsums.data_ptr(), dy.data_ptr())
-        return (dy, bsums[1].clone() if has_affine else None, bsums[0].clone() if has_affine else None,
+        return (dy, bsums[1] if has_affine else None, bsums[0] if has_affine else None,
                 None, None, None, None, None, None, None, None)
 
 

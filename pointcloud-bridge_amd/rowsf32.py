@@ -39,11 +39,11 @@ class _RowsLinear(torch.autograd.Function):
                 _launch("pcb_rows_linear_dgrad_f32", P * Ci * Co, g.data_ptr(), w.data_ptr(), P, Ci, Co, dx.data_ptr())
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 parts = _lib.load().pcb_rows_linear_wgrad_partials(P)
-                slabs = torch.empty(parts, Co, Ci + 1, dtype=torch.float32, device=x.device)
+                slabs = torch.empty(parts, Co * Ci + Co, dtype=torch.float32, device=x.device)
                 _launch("pcb_rows_linear_wgrad_f32", P * Ci * Co, g.data_ptr(), x.data_ptr(), P, Ci, Co, slabs.data_ptr())
-                total = sum_slabs(slabs)
-                dw = total[:, :Ci].contiguous()
-                db = total[:, Ci].contiguous() if ctx.has_bias else None
+                total = sum_slabs(slabs)          # [Co*Ci | Co]: both gradients are contiguous views of it
+                dw = total[:Co * Ci].view(Co, Ci)
+                db = total[Co * Ci:] if ctx.has_bias else None
         return dx, dw, db
 
 
@@ -109,7 +109,8 @@ class _NarrowBNAct(torch.autograd.Function):
             _launch("pcb_rows_bn_act_bwd_apply_f32", R * C, g.data_ptr(), x.data_ptr(), consts[0].data_ptr(),
                     consts[1].data_ptr(), consts[2].data_ptr(), consts[3].data_ptr(), sums.data_ptr(), R, C, act, training,
                     dx.data_ptr())
-        return (dx, sums[1].clone() if has_affine else None, sums[0].clone() if has_affine else None,
+        # (dgamma / dbeta as rows of the freshly summed [2, C] tensor: views, no copy launches)
+        return (dx, sums[1] if has_affine else None, sums[0] if has_affine else None,
                 None, None, None, None, None, None, None)
 
 

@@ -16,3 +16,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _engine_defaults():
+    """Every test starts from the package's defaults: scripts under test (bench.Run) set the THREAD default precision, a
+    static sampling pipeline or the scene shard for themselves; a test that relies on a default must not depend on which
+    test ran before it."""
+    try:
+        from pointcloud_bridge_amd import rowmlp
+        from pointcloud_bridge_amd.models import pointnet2_utils as pu
+    except Exception:   # (collection on a box without the built library: nothing to reset)
+        yield
+        return
+    rowmlp.set_precision("fp32")
+    pu.set_static_sampling(None)
+    pu.set_scene_shard(0, 1)
+    yield
