@@ -11,7 +11,7 @@ args = types.SimpleNamespace(no_dropout=False, no_prefetch=False, dump=None, gra
 from pointcloud_bridge_amd import parallel
 parallel.init_from_env()
 dev = torch.device("cuda", 0)
-run = bench.Run(args, model, "bf16", 16, 16384, 0, 1, dev, "train", "ball", True, "ce", False, False)
+run = bench.Run(args, model, "bf16", (8 if model == "dgcnn" else 16), (8192 if model == "dgcnn" else 16384), 0, 1, dev, "train", "ball", True, "ce", False, False)
 for _ in range(3): run.eager_step()
 torch.cuda.synchronize()
 SKIP = {"size", "dim", "view", "reshape", "data_ptr", "is_contiguous", "stride", "__get__", "numel", "expand", "transpose",
