@@ -902,6 +902,9 @@ def extras(args, device):
                                                              loss="bridge")),
         ("pn2_msg_infer_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, mode="infer")),
         ("pn2_msg_infer_graph_B16_N16384_bf16", dict(model_name="pn2_msg", precision="bf16", B=16, N=16384, mode="infer", graph=True)),
+        # the ONE configuration the reference publishes a number for (model_performance_comparison.csv:4: PointNet2 SSG, eval
+        # forward, B=4 x N=4096, fp32, 35 557 points/s on an RTX 4090): `vs_published` in this row
+        ("pn2_ssg_infer_published_B4_N4096_fp32", dict(model_name="pn2_ssg", precision="fp32", B=4, N=4096, mode="infer", graph=True)),
         # cfg5 as the reference runs it (inference_ptv3.py:48-51, :101-105) and on tiles of 16384 points
         ("ptv3_infer_B8_N4096_bf16", dict(model_name="ptv3", precision="bf16", B=8, N=4096, mode="infer")),
         ("ptv3_infer_B2_N16384_bf16", dict(model_name="ptv3", precision="bf16", B=2, N=16384, mode="infer")),
@@ -910,7 +913,7 @@ def extras(args, device):
         try:
             torch.cuda.empty_cache()
             run = Run(args, rank=0, world=1, device=device, **kw)
-            res = run.timed(8, 4)
+            res = run.timed(40, 10) if kw.get("mode") == "infer" else run.timed(8, 4)   # (an inference pass is 1-3 ms)
             run.close()
             launches = res["nt_launches"]
             entry = {"ms_per_step": res["ms_per_step"], "points_per_s": res["points_per_s"], "loss": res["loss"],
@@ -927,6 +930,8 @@ def extras(args, device):
                                          "traffic": None, "launches": launches,
                                          "note": "HIP events around the family's launches in the timed region of this run "
                                                  "(eager step, GEMMs of concurrent chains share the chip)"}
+            if name.startswith("pn2_ssg_infer_published"):
+                entry["vs_published"] = res["points_per_s"] / 35557.0
             if kw["model_name"] == "dgcnn" and not kw.get("graph"):
                 entry["roofline"] = knn_roofline(kw["B"], kw["N"], device)
             out[name] = entry
