@@ -744,6 +744,20 @@ int pcb_repeat_concat_bwd_f32(int n, const void *g, const int *rep, const int *w
 int pcb_attention_fwd_bf16(const void *qkv, int B, int N, int H, int D, float scale, void *out, void *stream);
 
 /*
+ * Row kernels of the transformer token pipeline around it (models/PointTransformerV3.py:119-148 PointTransformerBlock,
+ * :8-21 GEGLU), bf16 rows [R, C], inference:
+ *   pcb_add_layernorm_bf16   x' = x + h (h optional: the pending residual; xout, optional, receives x' -- the new residual
+ *                            stream, rounded to bf16); out = LayerNorm(x') * gamma + beta (+ pos, optional): `x = x +
+ *                            attn(norm1(x) + pos)` / `x = x + mlp(norm2(x))` without separate add / cast / normalise passes.
+ *                            fp32 statistics over the row (biased variance, eps as nn.LayerNorm), C a multiple of 8, <= 1024.
+ *   pcb_geglu_bf16           out [R, H] = y[:, :H] * gelu(y[:, H:]) for the projection rows y [R, 2H] (erf form: F.gelu's
+ *                            default), H a multiple of 8.
+ */
+int pcb_add_layernorm_bf16(const void *x, const void *h, const void *pos, const float *gamma, const float *beta, float eps,
+                           long R, int C, void *xout, void *out, void *stream);
+int pcb_geglu_bf16(const void *y, long R, int H, void *out, void *stream);
+
+/*
  * A whole stack of L <= PCB_STACK_MAX_LAYERS shared-MLP layers  x -> act(BN(x W^T + b))  [-> max over
  * each `pool` consecutive rows]  enqueued from ONE call -- the loop the reference writes as
  *   for i, conv in enumerate(self.mlp_convs): new_points = F.relu(self.mlp_bns[i](conv(new_points)))

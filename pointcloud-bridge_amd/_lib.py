@@ -122,6 +122,8 @@ SIGNATURES = {
     "pcb_repeat_concat_bwd_bf16": [_i, _p, _p, _p, _l, _p, _p],
     "pcb_repeat_concat_bwd_f32": [_i, _p, _p, _p, _l, _p, _p],
     "pcb_attention_fwd_bf16": [_p, _i, _i, _i, _i, _f, _p, _p],
+    "pcb_add_layernorm_bf16": [_p, _p, _p, _p, _p, _f, _l, _i, _p, _p, _p],
+    "pcb_geglu_bf16": [_p, _l, _i, _p, _p],
     "pcb_scene_colsum_workspace": [_i, _i, _i],
     "pcb_scene_concat_bf16": [_p, _p, _i, _i, _i, _i, _p, _p],
     "pcb_scene_concat_f32": [_p, _p, _i, _i, _i, _i, _p, _p],

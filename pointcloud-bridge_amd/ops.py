@@ -293,6 +293,39 @@ def attention(qkv, num_heads, scale=None):
     return out
 
 
+def add_layernorm(x, h, pos, norm, want_sum=False):
+    """Token rows x [.., C] bf16: x' = x + h (h may be None), LayerNorm(x') with `norm`'s parameters (+ pos, may be None)
+    in one pass (csrc/tokens.hip).  Returns (x' or None, normalised rows); x' only when want_sum and h is given.
+    Inference helper of models/PointTransformerV3.py (:119-148): no autograd."""
+    _need_cuda(x)
+    C = x.shape[-1]
+    xr = x.detach().reshape(-1, C)
+    R = xr.shape[0]
+    for t in (xr, h, pos):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or t.numel() != R * C):
+            raise ValueError("add_layernorm: contiguous bf16 rows of one shape")
+    g, b = norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous()
+    out = torch.empty_like(xr)
+    xout = torch.empty_like(xr) if (want_sum and h is not None) else None
+    with on_device(x.device):
+        _launch("pcb_add_layernorm_bf16", R * C, xr.data_ptr(), 0 if h is None else h.data_ptr(), 0 if pos is None else pos.data_ptr(),
+                g.data_ptr(), b.data_ptr(), float(norm.eps), R, C, 0 if xout is None else xout.data_ptr(), out.data_ptr())
+    return (None if xout is None else xout.view(x.shape)), out.view(x.shape)
+
+
+def geglu(y):
+    """y [.., 2H] bf16 -> y[.., :H] * gelu(y[.., H:]) in one pass (csrc/tokens.hip; models/PointTransformerV3.py:8-21)."""
+    _need_cuda(y)
+    H = y.shape[-1] // 2
+    yr = y.detach().reshape(-1, 2 * H)
+    if yr.dtype != torch.bfloat16 or not yr.is_contiguous() or H % 8:
+        raise ValueError("geglu: contiguous bf16 rows, half width a multiple of 8")
+    out = torch.empty(yr.shape[0], H, dtype=torch.bfloat16, device=y.device)
+    with on_device(y.device):
+        _launch("pcb_geglu_bf16", yr.numel(), yr.data_ptr(), yr.shape[0], H, out.data_ptr())
+    return out.view(*y.shape[:-1], H)
+
+
 def knn(x_bnd, k):
     """kNN graph on x [B,N,D] (DGCNN.py:49-70 after its transpose at :60) -> [B,N,k] int64."""
     _need_cuda(x_bnd)

@@ -104,3 +104,66 @@ def test_ptv3_logits_against_the_reference_fixture(monkeypatch):
         assert model.blocks[0].attn.qkv.weight.grad is not None
     finally:
         rowmlp.set_precision("fp32")
+
+
+@pytest.mark.parametrize("R,C", [(1000, 384), (77, 96), (4096, 768), (33, 1024)])
+@pytest.mark.parametrize("with_h,with_pos", [(False, True), (True, False), (True, True), (False, False)])
+def test_add_layernorm_rows(R, C, with_h, with_pos):
+    """pcb_add_layernorm_bf16 (csrc/tokens.hip) against nn.LayerNorm in fp32 on the same bf16 rows:
+    `x = x + attn(norm1(x) + pos)` / `x = x + mlp(norm2(x))` of PointTransformerBlock.forward (:140-147) as one pass each."""
+    from pointcloud_bridge_amd import ops
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) * 2 + 0.5).cuda().to(torch.bfloat16)
+    h = torch.randn(R, C, generator=g).cuda().to(torch.bfloat16) if with_h else None
+    pos = torch.randn(R, C, generator=g).cuda().to(torch.bfloat16) if with_pos else None
+    norm = torch.nn.LayerNorm(C, eps=1e-6).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    xs, out = ops.add_layernorm(x, h, pos, norm, want_sum=True)
+    x_ref = x.float() if h is None else (x.float() + h.float()).to(torch.bfloat16).float()
+    if h is None:
+        assert xs is None
+    else:
+        assert torch.equal(xs.float(), x_ref)                                   # the new residual stream, one rounding
+    ref = torch.nn.functional.layer_norm(x_ref, (C,), norm.weight, norm.bias, 1e-6)
+    if pos is not None:
+        ref = ref + pos.float()
+    err = (out.float() - ref).abs()
+    assert float(err.max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-6          # one bf16 rounding of the result
+    assert float(err.mean()) <= 2 ** -9 * float(ref.abs().mean())
+
+
+@pytest.mark.parametrize("R,H", [(1000, 1536), (31, 64), (4096, 384)])
+def test_geglu_rows(R, H):
+    """pcb_geglu_bf16 against x * F.gelu(gate) in fp32 (models/PointTransformerV3.py:8-21)."""
+    from pointcloud_bridge_amd import ops
+    g = torch.Generator().manual_seed(R + H)
+    y = (torch.randn(R, 2 * H, generator=g) * 1.5).cuda().to(torch.bfloat16)
+    out = ops.geglu(y)
+    a, gate = y.float().chunk(2, dim=-1)
+    ref = a * torch.nn.functional.gelu(gate)
+    err = (out.float() - ref).abs()
+    assert out.shape == (R, H)
+    assert float((err / (ref.abs() + 1e-3)).max()) <= 2 ** -8 * 1.01 + 1e-6
+
+
+def test_ptv3_fused_rows_equal_the_aten_rows(monkeypatch):
+    """The fused row path of the bf16 inference pass (two add+LayerNorm launches and one GEGLU launch per block, cached
+    bf16 weights) against the same pass on ATen row ops: logits within bf16 distance, same predictions."""
+    from tests.helpers import load_golden
+    from pointcloud_bridge_amd import rowmlp
+    from pointcloud_bridge_amd.models import PointTransformerV3 as mod
+    g = load_golden("model_ptv3")
+    xyz, colors = torch.from_numpy(g["xyz"]).cuda(), torch.from_numpy(g["colors"]).cuda()
+    model = _ptv3(g)
+    with rowmlp.precision("bf16"), torch.no_grad():
+        monkeypatch.setattr(mod, "_ROWS_FUSED", True)
+        fused = model(xyz, colors).float()
+        again = model(xyz, colors).float()          # (cached bf16 weights on the second call)
+        monkeypatch.setattr(mod, "_ROWS_FUSED", False)
+        aten = model(xyz, colors).float()
+    assert torch.equal(fused, again)
+    scale = float(aten.abs().max())
+    assert float((fused - aten).abs().max()) < 2e-2 * scale
+    assert float((fused.argmax(-1) == aten.argmax(-1)).float().mean()) > 0.99
