@@ -39,7 +39,7 @@ constexpr int AT_KT = 64;                    // keys per tile
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 
 template <int D>
-__global__ __launch_bounds__(AT_THREADS, 2) void attention_fwd_bf16_kernel(const u16 *__restrict__ qkv, int N, int H,
+__global__ __launch_bounds__(AT_THREADS, 1) void attention_fwd_bf16_kernel(const u16 *__restrict__ qkv, int N, int H,
                                                                           float scale_log2e, u16 *__restrict__ out)
 {
     static_assert(D % 32 == 0 && D <= 256, "head dimension: a multiple of 32 up to 256");
@@ -116,58 +116,73 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_fwd_bf16_kernel(const
         if (j + 1 < tiles) fetch((j + 1) * AT_KT);
         const u16 *const Kt = Ks + buf * AT_KT * KLD;
         const u16 *const Vt = Vs + buf * AT_KT * VLD;
+        // S^T for both 32-key blocks of the tile at once: two independent accumulator chains keep the matrix pipe issuing
+        // (one chain of D/16 dependent MFMAs left it waiting on its own result between instructions), ONE online-softmax
+        // step per 64 keys.  (Tried on top and dropped: the second block's products and the first block's V^T P^T placed
+        // between the softmax instructions of the other block, one wave overlapping its own matrix and vector work: 366
+        // against 364 us at cfg5's shape -- the partner wave of the SIMD already fills those gaps.)
+        static_assert(AT_KT == 64, "two 32-key blocks per tile");
+        f32x16 s0, s1;
 #pragma unroll
-        for (int kb = 0; kb < AT_KT / 32; ++kb) {
-            f32x16 s;
+        for (int i = 0; i < 16; ++i) {
+            s0[i] = 0.0f;
+            s1[i] = 0.0f;
+        }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Kt[(kb * 32 + (lane & 31)) * KLD + ks * 16 + hh * 8]);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
-            }
-            // s[i] = <k, q> for key = j*64 + kb*32 + 4*hh + (i&3) + 8*(i>>2), query = this lane's
-            const int key_lo = j * AT_KT + kb * 32 + 4 * hh;
-            float mx = -INFINITY;
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(&Kt[(lane & 31) * KLD + ks * 16 + hh * 8]);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(&Kt[(32 + (lane & 31)) * KLD + ks * 16 + hh * 8]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+        }
+        // s0[i] / s1[i] = <k, q> for key = j*64 + {0, 32} + 4*hh + (i&3) + 8*(i>>2), query = this lane's (unscaled)
+        if ((j + 1) * AT_KT > N) {   // (workgroup-uniform) the last, ragged tile: keys past the cloud drop out
+            const int key_lo = j * AT_KT + 4 * hh;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = key_lo + (i & 3) + 8 * (i >> 2);
-                s[i] = key < N ? s[i] * scale_log2e : -INFINITY;
-                mx = fmaxf(mx, s[i]);
+                s0[i] = key < N ? s0[i] : -INFINITY;
+                s1[i] = key + 32 < N ? s1[i] : -INFINITY;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);   // finite from the first tile on (key 0 exists)
-            const float alpha = m_run == -INFINITY ? 0.0f : exp2f(m_run - m_new);
-            float psum = 0.0f;
-            float p[16];
+        }
+        float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                p[i] = exp2f(s[i] - m_new);
-                psum += p[i];
-            }
-            psum += __shfl_xor(psum, 32);
-            l_run = fmaf(l_run, alpha, psum);
-            m_run = m_new;
-            // the running maximum settles after the first tiles: rescale only when some query's changed
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // scale > 0: the maximum of the scaled scores is the scaled maximum (rounding is monotonic)
+        const float m_new = fmaxf(m_run, mx * scale_log2e);   // finite from the first tile on (key 0 exists)
+        const float alpha = m_run == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.0f;
+        float p[32];
 #pragma unroll
-                for (int d = 0; d < DT; ++d)
+        for (int i = 0; i < 16; ++i) {
+            // exp2(s * scale - m) with the hardware exponential (arguments <= 0; below -126 it returns 0, as wanted)
+            p[i] = __builtin_amdgcn_exp2f(fmaf(s0[i], scale_log2e, -m_new));
+            p[16 + i] = __builtin_amdgcn_exp2f(fmaf(s1[i], scale_log2e, -m_new));
+            psum += p[i] + p[16 + i];
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+        // the running maximum settles after the first tiles: rescale only when some query's changed
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
-            }
+            for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                bf16x8 pf;
+                for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (short)f2bf(p[blk * 8 + e]);
+        for (int blk = 0; blk < 4; ++blk) {   // 16 keys each: blocks 0, 1 of the first 32, 2, 3 of the second
+            bf16x8 pf;
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    const u16 *pv = &Vt[(kb * 32 + blk * 16 + tr_row) * VLD + d * 32 + tr_col];
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pv);
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pv + 8 * VLD));
-                    const bf16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, o[d], 0, 0, 0);
-                }
+            for (int e = 0; e < 8; ++e) pf[e] = (short)f2bf(p[blk * 8 + e]);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const u16 *pv = &Vt[(blk * 16 + tr_row) * VLD + d * 32 + tr_col];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)pv);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pv + 8 * VLD));
+                const bf16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, o[d], 0, 0, 0);
             }
         }
         if (j + 1 < tiles) stage(buf ^ 1);
