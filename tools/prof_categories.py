@@ -13,7 +13,7 @@ FAMILIES = (("bwd_fused", "bwd_fused (dx + dW + sums, one pass)"), ("gemm_nt", "
             ("at::native", "ATen"), ("rocprim", "ATen"), ("Cijk", "hipBLASLt"), ("copyBuffer", "memcpy"), ("fillBuffer", "memset"), ("copy_list", "copy_table / copy_list"), ("copy_table", "copy_table / copy_list"),
             ("ce_", "cross entropy"), ("cew_", "cross entropy"), ("bridge_", "bridge loss weights"), ("rows_bn", "narrow BatchNorm rows"), ("scene_sum", "narrow BatchNorm rows"),
             ("segment_sum", "segment sums (reproducible mode)"), ("dropout", "dropout"), ("dy_repeat", "dy_repeat_sums / dy_rows"), ("dy_rows", "dy_repeat_sums / dy_rows"),
-            ("zero2", "zero / pad"), ("zero_kernel", "zero / pad"), ("pad_rows", "zero / pad"), ("scene_", "scene pool / concat"), ("repeat_concat", "repeat_concat"), ("attention", "attention"))
+            ("zero2", "zero / pad"), ("zero_kernel", "zero / pad"), ("pad_rows", "zero / pad"), ("scene_", "scene pool / concat"), ("repeat_concat", "repeat_concat"), ("attention", "attention"), ("add_layernorm", "token rows (add+LayerNorm, GEGLU)"), ("geglu", "token rows (add+LayerNorm, GEGLU)"))
 tot = {}
 rows = list(csv.DictReader(open(f)))
 if steps == 0:
