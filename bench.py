@@ -128,7 +128,8 @@ def cpu_baseline(model_name, N, budget_s=25.0):
     t0 = time.perf_counter()
     step()  # warm-up, also tells how many timed steps fit the budget
     first = time.perf_counter() - t0
-    n = max(1, min(5, int((budget_s - first) / max(first, 1e-3))))
+    # a bounded sample of 10-20 s of CPU work: as many steps as fit `budget_s` after the warm-up, 20 at most
+    n = max(1, min(20, int((min(budget_s, 16.0) - first) / max(first, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
         step()
