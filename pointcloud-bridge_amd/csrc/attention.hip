@@ -79,25 +79,35 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attention_fwd_bf16_kernel(const
         for (int i = 0; i < 16; ++i) o[d][i] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
-    // tile staging: chunk c of the tile = (key c / CH, 16-byte piece c % CH)
-    uint4 rk[NLOAD], rv[NLOAD];
-    auto fetch = [&](int key0) {
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int c = t + i * AT_THREADS;
-            const int key = key0 + c / CH;
-            const long off = (long)(key < N ? key : N - 1) * tok + (c % CH) * 8;
-            rk[i] = *reinterpret_cast<const uint4 *>(kbase + off);
-            rv[i] = *reinterpret_cast<const uint4 *>(vbase + off);
-        }
+    // tile staging: chunk c of the tile = (key c / CH, 16-byte piece c % CH).  The staged chunks are NAMED registers, not
+    // arrays: as `uint4 rk[NLOAD]` they lived in scratch memory (private stack: 32 NLOAD bytes per lane) -- every tile's
+    // global loads were waited for on the spot, stored to scratch and read back for the LDS write.
+    static_assert(NLOAD >= 1 && NLOAD <= 4, "staging registers");
+    uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    rk0 = rk1 = rk2 = rk3 = rv0 = rv1 = rv2 = rv3 = make_uint4(0u, 0u, 0u, 0u);
+    auto fetch1 = [&](int key0, int i, uint4 &k, uint4 &v) __attribute__((always_inline)) {
+        const int c = t + i * AT_THREADS;
+        const int key = key0 + c / CH;
+        const long off = (long)(key < N ? key : N - 1) * tok + (c % CH) * 8;
+        k = *reinterpret_cast<const uint4 *>(kbase + off);
+        v = *reinterpret_cast<const uint4 *>(vbase + off);
     };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int c = t + i * AT_THREADS;
-            *reinterpret_cast<uint4 *>(&Ks[(buf * AT_KT + c / CH) * KLD + (c % CH) * 8]) = rk[i];
-            *reinterpret_cast<uint4 *>(&Vs[(buf * AT_KT + c / CH) * VLD + (c % CH) * 8]) = rv[i];
-        }
+    auto fetch = [&](int key0) __attribute__((always_inline)) {
+        fetch1(key0, 0, rk0, rv0);
+        if (NLOAD > 1) fetch1(key0, 1, rk1, rv1);
+        if (NLOAD > 2) fetch1(key0, 2, rk2, rv2);
+        if (NLOAD > 3) fetch1(key0, 3, rk3, rv3);
+    };
+    auto stage1 = [&](int buf, int i, const uint4 &k, const uint4 &v) __attribute__((always_inline)) {
+        const int c = t + i * AT_THREADS;
+        *reinterpret_cast<uint4 *>(&Ks[(buf * AT_KT + c / CH) * KLD + (c % CH) * 8]) = k;
+        *reinterpret_cast<uint4 *>(&Vs[(buf * AT_KT + c / CH) * VLD + (c % CH) * 8]) = v;
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        stage1(buf, 0, rk0, rv0);
+        if (NLOAD > 1) stage1(buf, 1, rk1, rv1);
+        if (NLOAD > 2) stage1(buf, 2, rk2, rv2);
+        if (NLOAD > 3) stage1(buf, 3, rk3, rv3);
     };
     // transpose-read addressing (see csrc/gemm.hip, gemm_tn): lane 4q+p of a 16-lane group supplies row q,
     // columns 4p..4p+3 of a 4 x 16 block and receives column (lane & 15) of it; groups 0/1 cover columns 0-15 /

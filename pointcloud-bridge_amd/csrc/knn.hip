@@ -448,33 +448,34 @@ __global__ __launch_bounds__(kThreads, 2) void knn_screen_kernel(const float *__
         cap = h ? merged_worst : cap;
     };
 
-    uint4 pre[2][NV];
+    // staged chunks in NAMED registers (as `uint4 pre[2][NV]` behind conditional loads they lived in scratch memory:
+    // every stage's global loads were waited for on the spot, stored to the private stack and read back for the LDS write)
+    static_assert(NV >= 1 && NV <= 2, "staging registers");
+    uint4 ph0, ph1, pl0, pl1;
+    ph0 = ph1 = pl0 = pl1 = make_uint4(0u, 0u, 0u, 0u);
     float pre_n = 0.0f;
-    auto fetch = [&](int base) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e8 = t + i * kThreads;
-            const int m = e8 / (DP / 8), c = (e8 % (DP / 8)) * 8;
-            const int row = base + m;
-            uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
-            if (row < N) {
-                vh = *reinterpret_cast<const uint4 *>(xhb + (size_t)row * DP + c);
-                vl = *reinterpret_cast<const uint4 *>(xlb + (size_t)row * DP + c);
-            }
-            pre[0][i] = vh;
-            pre[1][i] = vl;
-        }
+    auto fetch1 = [&](int base, int i, uint4 &vh, uint4 &vl) __attribute__((always_inline)) {
+        const int e8 = t + i * kThreads;
+        const int m = e8 / (DP / 8), c = (e8 % (DP / 8)) * 8;
+        const int row = base + m < N ? base + m : N - 1;   // (rows past the cloud: any finite data -- their key term is infinite)
+        vh = *reinterpret_cast<const uint4 *>(xhb + (size_t)row * DP + c);
+        vl = *reinterpret_cast<const uint4 *>(xlb + (size_t)row * DP + c);
+    };
+    auto fetch = [&](int base) __attribute__((always_inline)) {
+        fetch1(base, 0, ph0, pl0);
+        if (NV > 1) fetch1(base, 1, ph1, pl1);
         // (no arithmetic on the loaded value here: it would wait for the loads of the whole stage)
         if (t < kTC) pre_n = base + t < N ? nb[base + t] : INFINITY;
     };
-    auto stash = [&](int buf, int ring) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e8 = t + i * kThreads;
-            const int m = e8 / (DP / 8), c = (e8 % (DP / 8)) * 8;
-            *reinterpret_cast<uint4 *>(&tiles[buf][0][m * LD + c]) = pre[0][i];
-            *reinterpret_cast<uint4 *>(&tiles[buf][1][m * LD + c]) = pre[1][i];
-        }
+    auto stash1 = [&](int buf, int i, const uint4 &vh, const uint4 &vl) __attribute__((always_inline)) {
+        const int e8 = t + i * kThreads;
+        const int m = e8 / (DP / 8), c = (e8 % (DP / 8)) * 8;
+        *reinterpret_cast<uint4 *>(&tiles[buf][0][m * LD + c]) = vh;
+        *reinterpret_cast<uint4 *>(&tiles[buf][1][m * LD + c]) = vl;
+    };
+    auto stash = [&](int buf, int ring) __attribute__((always_inline)) {
+        stash1(buf, 0, ph0, pl0);
+        if (NV > 1) stash1(buf, 1, ph1, pl1);
         // |x_j|^2 (1 - c): the key's candidate term; a candidate beyond the cloud gets an infinite one and never passes
         if (t < kTC) cnrms[ring][t] = pre_n * (1.0f - kC);
     };
